@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config.
+
+metric : 1920x1080 RGB24 frames/sec through diff + threshold + pack (+ achieved HBM GB/s vs peak)
+config : configs[1] "1080p30 synthetic stream, diff+threshold+pack on 1xMI355X": the S1 `webcam`
+         stream resident in HBM as a batch of B frames; one step = one pass of the
+         hot path (mi355_diff_stream_batch: pack kernel + scans + gather kernel) over that batch,
+         the stream state carried from step to step.  Inputs are already in HBM when the timed region
+         starts.
+N GPUs : one process per GPU (torch.distributed, backend nccl = RCCL); every rank runs an independent
+         stream of the same shape (weak scaling, no data-path collective).  The exchange step is the
+         gather of the per-frame index to rank 0 every step plus ONE gather-v of the final batch's
+         changed-pixel payload inside the timed region (--gather every|last|index|none).
+
+Prints ONE JSON line on rank 0.  The CPU oracle is used only as the checker / cpu_baseline leg.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from cudavideostream_amd import CUDACore, synth  # noqa: E402
+from cudavideostream_amd import gather as gx  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=100)
+    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--batch", type=int, default=256, help="frames per step (resident in HBM)")
+    p.add_argument("--width", type=int, default=1920)
+    p.add_argument("--height", type=int, default=1080)
+    p.add_argument("--gather", choices=["every", "last", "index", "none"], default="last")
+    p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    p.add_argument("--no-cpu", action="store_true")
+    p.add_argument("--no-pair", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(args, base, frames, dev):
+    """Oracle (CPU restatement of tests/cuda_streaming/test.cu:560-576) on a bounded sample of the
+    same stream, single-threaded like the reference's elaboration thread; also the parity check of
+    the GPU path on that sample."""
+    from oracle import pyoracle as po
+    n = base.numel()
+    h_base = base.cpu().numpy()
+    f0 = frames[0].cpu().numpy()
+    t = time.perf_counter()
+    po.diff_pack(f0, h_base)
+    t_one = max(time.perf_counter() - t, 1e-4)
+    S = int(max(4, min(frames.shape[0], 96, args.cpu_seconds / t_one)))
+    h_frames = frames[:S].cpu().numpy()
+    t = time.perf_counter()
+    eo, exs, edf, est = po.diff_stream(h_frames, h_base)
+    dt = time.perf_counter() - t
+    ncores = os.cpu_count() or 1
+    st = h_base.copy()
+    t = time.perf_counter()
+    for i in range(min(S, 16)):
+        _, _, _, st = po.diff_pack_mt(h_frames[i], st, nthreads=ncores)
+    dt_mt = (time.perf_counter() - t) / min(S, 16)
+    # parity of the product path on the same sample
+    with CUDACore(args.width, args.height, max_batch=S) as c2:
+        c2.use_torch_stream()
+        c2.set_state(h_base)
+        cap = int(eo[-1]) + 16
+        d_off = torch.zeros(S + 1, dtype=torch.int32, device=dev)
+        d_xs = torch.empty(cap, dtype=torch.int32, device=dev)
+        d_df = torch.empty(cap, dtype=torch.uint8, device=dev)
+        c2.diff_stream_batch(frames, S, d_off, d_xs, d_df, cap)
+        torch.cuda.synchronize()
+        ok = (np.array_equal(d_off.cpu().numpy().view(np.uint32), eo)
+              and np.array_equal(d_xs[:int(eo[-1])].cpu().numpy(), exs)
+              and np.array_equal(d_df[:int(eo[-1])].cpu().numpy(), edf)
+              and np.array_equal(c2.get_state(), est))
+    base_obj = {"value": round(S / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": f"first {S} frames of the same {args.width}x{args.height} S1 stream, "
+                          f"oracle/cpu_ref.c ora_diff_stream, {dt:.2f} s",
+                "all_cores": {"value": round(1.0 / dt_mt, 2), "unit": "frames/s", "cores": ncores,
+                              "sample": f"{min(S, 16)} frames, row-band pthreads"}}
+    return base_obj, bool(ok)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    W, H, B, K = args.width, args.height, args.batch, args.steps
+    n = 3 * W * H
+    base, frames = synth.webcam_stream(B, W, H, seed=21 + rank, device=dev)
+    cap = max(B * n // 8, 1 << 20)
+    d_off = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    d_xs = torch.empty(cap, dtype=torch.int32, device=dev)
+    d_df = torch.empty(cap, dtype=torch.uint8, device=dev)
+
+    core = CUDACore(W, H, max_batch=B, device=local_rank)
+    core.use_torch_stream()
+    core.set_state(base.cpu().numpy())
+
+    def step(last):
+        core.diff_stream_batch(frames, B, d_off, d_xs, d_df, cap)
+        if world > 1:
+            if args.gather == "every" or (args.gather == "last" and last):
+                gx.gather_payload(d_off, d_xs, d_df, dst=0)
+            elif args.gather in ("index", "last"):
+                gx.gather_index(d_off, dst=0)
+
+    for i in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    core.set_timing(True)
+    core.reset_timing()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(i == K - 1)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_pack, ms_total, launches = core.get_timing()
+    core.set_timing(False)
+    off = d_off.cpu().numpy().view(np.uint32)
+    p_total = int(off[-1])
+    assert p_total <= cap, "output capacity too small for this stream"
+
+    if rank == 0:
+        pack_ms = ms_pack / max(launches, 1)
+        alg_bytes = 2.0 * n * B + 5.0 * p_total          # B_alg = 2N + 5P per frame
+        achieved = alg_bytes / (pack_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("batch") == B and rec.get("width") == W and rec.get("height") == H:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "1920x1080 RGB24 frames/sec (diff+threshold+pack); achieved HBM GB/s vs peak",
+            "value": round(world * B * K / elapsed, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / K * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": f"{W}x{H} BGR24 S1 webcam stream, {B}-frame batches resident in HBM, "
+                                   f"stateful diff+threshold(20)+pack, ordered output",
+                       "frames_per_step": B, "changed_bytes_per_frame": round(p_total / B, 1),
+                       "parallelism": f"{world} independent streams" if world > 1 else "1 stream",
+                       "gather": args.gather if world > 1 else "n/a"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": traffic,
+                         "kernel": "mi355::k_diff_pack<false,true>",
+                         "kernel_ms": round(pack_ms, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "read_gbps_2N": round(2.0 * n * B / (pack_ms * 1e-3) / 1e9, 1),
+                         "all_kernels_ms": round(ms_total / max(launches, 1), 4)},
+        }
+        if world == 1 and not args.no_pair:
+            out["pair_mode"] = pair_mode(args, core, frames, d_off, d_xs, d_df, cap, n)
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"], out["parity"] = cpu_baseline(args, base, frames, dev)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    core.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def pair_mode(args, core, frames, d_off, d_xs, d_df, cap, n):
+    """Secondary line: stateless frame pairs (cur = frame t, prev = frame t-1), i.e. 2N bytes of HBM
+    reads per frame with no reuse -- the plain streaming rate of the same kernel."""
+    B = frames.shape[0] - 1
+    core.set_timing(True)
+    core.reset_timing()
+    for _ in range(3):
+        core.diff_pairs_batch(frames[1:], frames[:-1], B, d_off, d_xs, d_df, cap)
+    torch.cuda.synchronize()
+    core.reset_timing()
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        core.diff_pairs_batch(frames[1:], frames[:-1], B, d_off, d_xs, d_df, cap)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms_pack, _, launches = core.get_timing()
+    core.set_timing(False)
+    p = int(d_off.cpu().numpy().view(np.uint32)[B])
+    pack_ms = ms_pack / max(launches, 1)
+    alg = 2.0 * n * B + 5.0 * p
+    return {"frames_per_s": round(B * reps / dt, 1), "kernel_ms": round(pack_ms, 4),
+            "achieved_gbps": round(alg / (pack_ms * 1e-3) / 1e9, 1),
+            "frac": round(alg / (pack_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "changed_bytes_per_frame": round(p / B, 1)}
+
+
+if __name__ == "__main__":
+    main()

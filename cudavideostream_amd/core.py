@@ -1,0 +1,199 @@
+"""Host-side mirror of the reference's operator for the hot path: ``diff::cuda::CUDACore``
+(server/include/kernels.cuh:13-43, server/src/kernels.cu:377-536), over the C-ABI of
+libmi355diff.so.  Same method names and argument meaning as the C++ class, plus the
+device-resident batch entry points used by the benchmark and the parity tests.
+
+PyTorch is used only as plumbing for device buffers / streams (``tensor.data_ptr()``); every
+computation happens in the HIP library.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _l
+
+CHARS_STR = "0123456789BFPSWbkps :/"  # server/include/common.h:13
+LR_THRESHOLDS = 20                     # server/include/common.h:14
+
+
+def _ptr(x):
+    """Device/host address of a torch tensor, numpy array, int or None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    return x.data_ptr()
+
+
+class PinnedArray:
+    """numpy view over hipHostMalloc'ed memory (CUDACore::alloc_arrays, kernels.cu:531-536)."""
+
+    def __init__(self, nbytes, dtype=np.uint8):
+        self._lib = _l.load()
+        p = C.c_void_p()
+        _l.check(self._lib.mi355_host_alloc(C.byref(p), nbytes))
+        self.ptr = p.value
+        buf = (C.c_uint8 * nbytes).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=np.uint8).view(dtype)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            _l.check(self._lib.mi355_host_free(self.ptr))
+            self.ptr = None
+
+
+class CUDACore:
+    """MI355X drop-in for the reference's CUDACore.
+
+    Reference constructor (kernels.cu:377): CUDACore(charsPx, charsSz, k, total, sampleMatData,
+    frameSz).  Here: the same data by keyword; `total` is implied by the frame size.
+    """
+
+    def __init__(self, width, height, k=None, sample_mat_data=None, chars_px=None, chars_sz=None,
+                 charset=CHARS_STR, threshold=LR_THRESHOLDS, max_batch=1, device=-1,
+                 noise_filter=False, visualizer=_l.VIS_NONE):
+        self._lib = _l.load()
+        self.width, self.height = int(width), int(height)
+        self.total = 3 * self.width * self.height
+        self.max_batch = int(max_batch)
+        cfg = _l.Config(self.width, self.height, int(threshold), self.max_batch, int(device),
+                        int(bool(noise_filter)), int(visualizer), 0)
+        h = C.c_void_p()
+        _l.check(self._lib.mi355_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        if k is not None:  # cudaMemcpyToSymbol(dev_k, ...) kernels.cu:394
+            k = np.ascontiguousarray(k, dtype=np.float32).reshape(-1)
+            assert k.size == 9
+            _l.check(self._lib.mi355_set_conv_kernel(self._h, k.ctypes.data))
+        if chars_px is not None:  # kernels.cu:379-382
+            gh, gw = chars_sz
+            chars_px = np.ascontiguousarray(chars_px, dtype=np.uint8).reshape(-1)
+            assert chars_px.size == len(charset) * 3 * gh * gw
+            _l.check(self._lib.mi355_set_glyphs(self._h, chars_px.ctypes.data, len(charset), gh, gw,
+                                                charset.encode()))
+        if sample_mat_data is not None:  # kernels.cu:406
+            self.set_state(sample_mat_data)
+
+    # -- life cycle -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mi355_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def workspace_bytes(self):
+        return self._lib.mi355_workspace_bytes(self._h)
+
+    def use_torch_stream(self):
+        import torch
+        _l.check(self._lib.mi355_set_stream(self._h, torch.cuda.current_stream().cuda_stream))
+
+    def synchronize(self):
+        _l.check(self._lib.mi355_synchronize(self._h))
+
+    # -- reference surface ------------------------------------------------------------------------
+    @staticmethod
+    def alloc_arrays(r, c):
+        """kernels.cu:531-536: three pinned 3rc(+slack) frames and one pinned 3rc int array."""
+        n = 3 * r * c
+        slack = CUDACore.chunkt_size()
+        h_frame = PinnedArray(n + slack)
+        n_frame = PinnedArray(n + slack)
+        o_frame = PinnedArray(n + slack)
+        h_xs = PinnedArray(n * 4 + slack, np.int32)
+        return h_frame, n_frame, o_frame, h_xs
+
+    @staticmethod
+    def chunkt_size():
+        """kernels.cu:527-529 returns sizeof(long4)=32, the reference's access granule; the slack a
+        caller must leave behind its buffers.  This implementation never touches bytes past N, the
+        value is kept for callers that size their buffers with it."""
+        return 32
+
+    def exec_core(self, frame_data, show_ready_n_data, text, h_xs):
+        """kernels.cu:430-525.  frame_data (uint8[>=N], in: frame, out: diff[0..h_pos)),
+        show_ready_n_data (uint8[>=N] or None), text (str), h_xs (int32[>=N]).  Returns h_pos."""
+        pos = C.c_uint32(0)
+        t = text.encode() if text else None
+        _l.check(self._lib.mi355_exec(self._h, _ptr(frame_data), _ptr(show_ready_n_data), t,
+                                      C.addressof(pos), _ptr(h_xs)))
+        return pos.value
+
+    # -- state ------------------------------------------------------------------------------------
+    def set_state(self, frame):
+        frame = np.ascontiguousarray(frame, dtype=np.uint8).reshape(-1)
+        assert frame.size == self.total
+        _l.check(self._lib.mi355_set_state(self._h, frame.ctypes.data))
+
+    def get_state(self):
+        out = np.empty(self.total, np.uint8)
+        _l.check(self._lib.mi355_get_state(self._h, out.ctypes.data))
+        return out
+
+    def state_ptr(self):
+        return self._lib.mi355_state_device_ptr(self._h)
+
+    # -- device-resident hot path -----------------------------------------------------------------
+    def diff_stream_batch(self, d_frames, nframes, d_offsets, d_xs, d_diff, capacity, stride=None):
+        stride = self.total if stride is None else stride
+        _l.check(self._lib.mi355_diff_stream_batch(self._h, _ptr(d_frames), stride, nframes,
+                                                   _ptr(d_offsets), _ptr(d_xs), _ptr(d_diff), capacity))
+
+    def diff_pairs_batch(self, d_cur, d_prev, nframes, d_offsets, d_xs, d_diff, capacity, stride=None):
+        stride = self.total if stride is None else stride
+        _l.check(self._lib.mi355_diff_pairs_batch(self._h, _ptr(d_cur), _ptr(d_prev), stride, nframes,
+                                                  _ptr(d_offsets), _ptr(d_xs), _ptr(d_diff), capacity))
+
+    def int_diff(self, d_cur, d_prev, d_out, n):
+        _l.check(self._lib.mi355_int_diff(self._h, _ptr(d_cur), _ptr(d_prev), _ptr(d_out), n))
+
+    # -- filters ----------------------------------------------------------------------------------
+    def gray_avg(self, d_in, d_out):
+        _l.check(self._lib.mi355_gray_avg(self._h, _ptr(d_in), _ptr(d_out)))
+
+    def gray_weighted(self, d_in, d_out):
+        _l.check(self._lib.mi355_gray_weighted(self._h, _ptr(d_in), _ptr(d_out)))
+
+    def binarize_chain(self, d_gray, d_out, d_hist=None, d_thr=None):
+        _l.check(self._lib.mi355_binarize_chain(self._h, _ptr(d_gray), _ptr(d_out), _ptr(d_hist),
+                                                _ptr(d_thr)))
+
+    def heat_map(self, d_cur, d_prev, d_out):
+        _l.check(self._lib.mi355_heat_map(self._h, _ptr(d_cur), _ptr(d_prev), _ptr(d_out)))
+
+    def red_dense(self, d_cur, d_prev, d_out):
+        _l.check(self._lib.mi355_red_dense(self._h, _ptr(d_cur), _ptr(d_prev), _ptr(d_out)))
+
+    def red_overlap(self, d_img, d_xs, d_count=None, count=0):
+        _l.check(self._lib.mi355_red_overlap(self._h, _ptr(d_img), _ptr(d_xs), _ptr(d_count), count))
+
+    def conv3x3(self, d_in, d_out):
+        _l.check(self._lib.mi355_conv3x3(self._h, _ptr(d_in), _ptr(d_out)))
+
+    # -- measurement ------------------------------------------------------------------------------
+    def set_timing(self, on):
+        _l.check(self._lib.mi355_set_timing(self._h, int(bool(on))))
+
+    def reset_timing(self):
+        _l.check(self._lib.mi355_reset_timing(self._h))
+
+    def get_timing(self):
+        """(ms in the diff/threshold/pack kernel, ms in pack+scan+gather, launches) since reset."""
+        a, b, n = C.c_double(0), C.c_double(0), C.c_int(0)
+        _l.check(self._lib.mi355_get_timing(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value

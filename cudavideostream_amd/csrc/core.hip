@@ -1,0 +1,515 @@
+// core.hip -- the C-ABI of libmi355diff.so (include/mi355diff.h): context, HBM layout, orchestration.
+//
+// Host-side counterpart of diff::cuda::CUDACore (reference server/src/kernels.cu:377-536).  HBM layout
+// of one core (N = 3*width*height, W = ceil(N/1024) tiles, T = max_batch):
+//   state     N            the client's reconstructed frame (d_current/d_previous pair of the
+//                          reference collapsed into one persistent buffer)
+//   in, aux, vis  N each   exec(): uploaded frame, filter scratch, visualisation frame
+//   log_xs    W*1024*T*4   per-tile append logs written by k_diff_pack (worst case: every byte of
+//   log_diff  W*1024*T     every frame flagged)
+//   cnt, logpos, segoff  T*W*4 each;  totals T*4;  offsets (T+1)*4
+//   one_xs N*4, one_diff N exec(): packed output of a single frame before the D2H copies
+//   hist 256*4, thr 4, k9 9*4, heat LUT 766*3, glyph atlas
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/mi355diff.h"
+#include "internal.h"
+
+using namespace mi355;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof buf, "%s: %s (%s)", what, hipGetErrorName(e), hipGetErrorString(e));
+    else
+        snprintf(buf, sizeof buf, "%s", what);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                             \
+    do {                                                          \
+        hipError_t _e = (expr);                                   \
+        if (_e != hipSuccess) return fail(MI355_ERR_HIP, #expr, _e); \
+    } while (0)
+
+}  // namespace
+
+struct mi355_core {
+    mi355_config cfg{};
+    int device = 0;
+    uint32_t n = 0;        // bytes per frame
+    uint32_t ntiles = 0;
+    uint32_t log_cap = 0;  // entries per tile log
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+
+    uint8_t *state = nullptr, *in = nullptr, *aux = nullptr, *vis = nullptr;
+    int32_t *log_xs = nullptr;
+    uint8_t *log_diff = nullptr;
+    uint32_t *cnt = nullptr, *logpos = nullptr, *segoff = nullptr, *totals = nullptr;
+    uint32_t *offsets = nullptr;  // T+1, used by exec()
+    int32_t *one_xs = nullptr;
+    uint8_t *one_diff = nullptr;
+    int32_t *hist = nullptr, *thr = nullptr;
+    float *k9 = nullptr;
+    uint8_t *lut = nullptr;
+    uint8_t *glyphs = nullptr;
+    int nglyphs = 0, glyph_h = 0, glyph_w = 0;
+    std::string charset;
+    bool have_k9 = false;
+    size_t workspace = 0;
+
+    uint32_t *h_count = nullptr;  // pinned, 2 x u32 (offsets[0..1] of exec)
+
+    // timing: ring of event triplets {before pack, after pack, after gather}, harvested lazily so
+    // that timed batches still queue back to back
+    static constexpr int kEvRing = 32;
+    bool timing = false;
+    hipEvent_t ev[kEvRing][3] = {};
+    int ev_head = 0, ev_count = 0;  // oldest pending slot, number pending
+    double ms_pack = 0, ms_total = 0;
+    int launches = 0;
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(mi355_core *c, T **p, size_t count) {
+    const size_t bytes = count * sizeof(T);
+    HIP_TRY(hipMalloc((void **)p, bytes ? bytes : 16));
+    c->workspace += bytes;
+    return MI355_OK;
+}
+
+int use_device(const mi355_core *c) {
+    HIP_TRY(hipSetDevice(c->device));
+    return MI355_OK;
+}
+
+// Fold pending event triplets into the sums: all of them (blocking) or only until `keep` remain.
+int harvest_timing(mi355_core *c, int keep = 0) {
+    while (c->ev_count > keep) {
+        hipEvent_t *e = c->ev[c->ev_head];
+        HIP_TRY(hipEventSynchronize(e[2]));
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, e[0], e[1]));
+        HIP_TRY(hipEventElapsedTime(&b, e[0], e[2]));
+        c->ms_pack += a;
+        c->ms_total += b;
+        c->launches += 1;
+        c->ev_head = (c->ev_head + 1) % mi355_core::kEvRing;
+        c->ev_count -= 1;
+    }
+    return MI355_OK;
+}
+
+// tests/heat_map_benchmark/cpu.cu:19-27 for d = 0..765, stored B,G,R (cpu.cu:62-64).
+void build_heat_lut(uint8_t *lut) {
+    for (int diff = 0; diff <= 765; diff++) {
+        float diff1 = diff / (255.0 * 2.0);
+        double r = sin(M_PI * diff1 - M_PI / 2.0) * 255.0;
+        double g = sin(M_PI * diff1) * 255.0;
+        double b = sin(M_PI * diff1 + M_PI / 2.0) * 255.0;
+        r = r > 0.0 ? r : 0.0; r = r < 255.0 ? r : 255.0;
+        g = g > 0.0 ? g : 0.0; g = g < 255.0 ? g : 255.0;
+        b = b > 0.0 ? b : 0.0; b = b < 255.0 ? b : 255.0;
+        lut[diff * 3 + 0] = (uint8_t)(int)b;
+        lut[diff * 3 + 1] = (uint8_t)(int)g;
+        lut[diff * 3 + 2] = (uint8_t)(int)r;
+    }
+}
+
+int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, size_t stride,
+              int nframes, void *d_offsets, void *d_xs, void *d_diff, size_t capacity) {
+    if (!c) return fail(MI355_ERR_INVALID, "null core");
+    if (nframes < 0 || nframes > c->cfg.max_batch)
+        return fail(MI355_ERR_INVALID, "nframes outside [0, max_batch]");
+    if (!d_offsets) return fail(MI355_ERR_INVALID, "null d_offsets");
+    if (nframes > 0 && (!d_cur || (pair && !d_prev))) return fail(MI355_ERR_INVALID, "null frame pointer");
+    if (nframes > 0 && stride < c->n) return fail(MI355_ERR_INVALID, "stride_bytes < frame bytes");
+    if (capacity > 0 && (!d_xs || !d_diff)) return fail(MI355_ERR_INVALID, "null output pointer");
+    if (int rc = use_device(c)) return rc;
+    if (nframes == 0 || c->n == 0) {
+        HIP_TRY(hipMemsetAsync(d_offsets, 0, sizeof(uint32_t) * ((size_t)nframes + 1), c->stream));
+        return MI355_OK;
+    }
+    hipEvent_t *tev = nullptr;
+    if (c->timing) {
+        if (int rc = harvest_timing(c, mi355_core::kEvRing - 1)) return rc;
+        tev = c->ev[(c->ev_head + c->ev_count) % mi355_core::kEvRing];
+        HIP_TRY(hipEventRecord(tev[0], c->stream));
+    }
+    PackArgs a{};
+    a.cur = (const uint8_t *)d_cur;
+    a.prev = (const uint8_t *)d_prev;
+    a.state = c->state;
+    a.stride = stride;
+    a.n = c->n;
+    a.nframes = nframes;
+    a.thr = c->cfg.threshold;
+    a.ntiles = c->ntiles;
+    a.log_cap = c->log_cap;
+    a.log_xs = c->log_xs;
+    a.log_diff = c->log_diff;
+    a.cnt = c->cnt;
+    a.logpos = c->logpos;
+    const bool aligned = (((uintptr_t)d_cur | (uintptr_t)d_prev | stride) & 15u) == 0;
+    HIP_TRY(launch_diff_pack(a, pair, aligned, c->stream));
+    if (tev) HIP_TRY(hipEventRecord(tev[1], c->stream));
+    HIP_TRY(launch_scan(c->cnt, c->segoff, c->totals, c->ntiles, nframes, (uint32_t *)d_offsets,
+                        c->stream));
+    GatherArgs g{};
+    g.log_xs = c->log_xs;
+    g.log_diff = c->log_diff;
+    g.cnt = c->cnt;
+    g.logpos = c->logpos;
+    g.segoff = c->segoff;
+    g.offsets = (const uint32_t *)d_offsets;
+    g.ntiles = c->ntiles;
+    g.log_cap = c->log_cap;
+    g.out_xs = (int32_t *)d_xs;
+    g.out_diff = (uint8_t *)d_diff;
+    g.capacity = capacity;
+    HIP_TRY(launch_gather(g, nframes, c->stream));
+    if (tev) {
+        HIP_TRY(hipEventRecord(tev[2], c->stream));
+        c->ev_count += 1;
+    }
+    return MI355_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mi355_last_error(void) { return g_err.c_str(); }
+
+int mi355_create(const mi355_config *cfg, mi355_core **out) {
+    if (!cfg || !out) return fail(MI355_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->width < 0 || cfg->height < 0) return fail(MI355_ERR_INVALID, "negative frame size");
+    if (cfg->threshold < 0 || cfg->threshold > 127) return fail(MI355_ERR_INVALID, "threshold outside 0..127");
+    if (cfg->max_batch < 1) return fail(MI355_ERR_INVALID, "max_batch < 1");
+    if (cfg->visualizer < 0 || cfg->visualizer > 5) return fail(MI355_ERR_INVALID, "unknown visualizer");
+    const uint64_t n64 = 3ull * (uint64_t)cfg->width * (uint64_t)cfg->height;
+    if (n64 >= (1ull << 31)) return fail(MI355_ERR_INVALID, "frame larger than 2 GiB");
+    // byte indices are int32 and batch offsets uint32 (the reference's h_xs / h_pos types)
+    if (n64 * (uint64_t)cfg->max_batch >= (1ull << 32))
+        return fail(MI355_ERR_INVALID, "max_batch * frame bytes must stay below 2^32");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(MI355_ERR_HIP, "no HIP device available (libmi355diff has no CPU fallback)", e);
+    mi355_core *c = new (std::nothrow) mi355_core;
+    if (!c) return fail(MI355_ERR_INVALID, "out of host memory");
+    c->cfg = *cfg;
+    if (cfg->device >= 0) c->device = cfg->device;
+    else if ((e = hipGetDevice(&c->device)) != hipSuccess) { delete c; return fail(MI355_ERR_HIP, "hipGetDevice", e); }
+    if (c->device >= ndev) { delete c; return fail(MI355_ERR_INVALID, "device ordinal out of range"); }
+
+    c->n = (uint32_t)n64;
+    c->ntiles = (c->n + kTileBytes - 1) / kTileBytes;
+    c->log_cap = kTileBytes * (uint32_t)cfg->max_batch;
+    const size_t T = (size_t)cfg->max_batch, W = c->ntiles, N = c->n;
+
+    int rc = use_device(c);
+    if (!rc) { e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipStreamCreate", e); }
+    c->stream = c->own_stream;
+    for (int i = 0; i < mi355_core::kEvRing * 3 && !rc; i++) { e = hipEventCreate(&c->ev[i / 3][i % 3]); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipEventCreate", e); }
+    if (!rc) rc = dev_alloc(c, &c->state, N + 16);
+    if (!rc) rc = dev_alloc(c, &c->in, N + 16);
+    if (!rc) rc = dev_alloc(c, &c->aux, N + 16);
+    if (!rc) rc = dev_alloc(c, &c->vis, N + 16);
+    if (!rc) rc = dev_alloc(c, &c->log_xs, W * c->log_cap);
+    if (!rc) rc = dev_alloc(c, &c->log_diff, W * c->log_cap);
+    if (!rc) rc = dev_alloc(c, &c->cnt, T * W);
+    if (!rc) rc = dev_alloc(c, &c->logpos, T * W);
+    if (!rc) rc = dev_alloc(c, &c->segoff, T * W);
+    if (!rc) rc = dev_alloc(c, &c->totals, T);
+    if (!rc) rc = dev_alloc(c, &c->offsets, T + 1);
+    if (!rc) rc = dev_alloc(c, &c->one_xs, N + 4);
+    if (!rc) rc = dev_alloc(c, &c->one_diff, N + 16);
+    if (!rc) rc = dev_alloc(c, &c->hist, 256);
+    if (!rc) rc = dev_alloc(c, &c->thr, 1);
+    if (!rc) rc = dev_alloc(c, &c->k9, 9);
+    if (!rc) rc = dev_alloc(c, &c->lut, 768 * 3);
+    if (!rc) { e = hipHostMalloc((void **)&c->h_count, 2 * sizeof(uint32_t), hipHostMallocDefault); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipHostMalloc", e); }
+    if (!rc) { e = hipMemset(c->state, 0, N + 16); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipMemset", e); }
+    if (!rc) {
+        uint8_t lut[768 * 3] = {0};
+        build_heat_lut(lut);
+        e = hipMemcpy(c->lut, lut, sizeof lut, hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipMemcpy(lut)", e);
+    }
+    if (rc) { mi355_destroy(c); return rc; }
+    *out = c;
+    return MI355_OK;
+}
+
+void mi355_destroy(mi355_core *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->log_xs, c->log_diff, c->cnt, c->logpos,
+                    c->segoff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
+                    c->lut, c->glyphs};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->h_count) (void)hipHostFree(c->h_count);
+    for (auto &slot : c->ev) for (auto &ev : slot) if (ev) (void)hipEventDestroy(ev);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+size_t mi355_frame_bytes(const mi355_core *c) { return c ? c->n : 0; }
+size_t mi355_workspace_bytes(const mi355_core *c) { return c ? c->workspace : 0; }
+
+int mi355_set_stream(mi355_core *c, void *hip_stream) {
+    if (!c) return fail(MI355_ERR_INVALID, "null core");
+    if (int rc = use_device(c)) return rc;
+    if (int rc = harvest_timing(c)) return rc;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return MI355_OK;
+}
+
+int mi355_synchronize(mi355_core *c) {
+    if (!c) return fail(MI355_ERR_INVALID, "null core");
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MI355_OK;
+}
+
+int mi355_set_state(mi355_core *c, const uint8_t *host_frame) {
+    if (!c || !host_frame) return fail(MI355_ERR_INVALID, "null argument");
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->state, host_frame, c->n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MI355_OK;
+}
+
+int mi355_get_state(mi355_core *c, uint8_t *host_frame) {
+    if (!c || !host_frame) return fail(MI355_ERR_INVALID, "null argument");
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(hipMemcpyAsync(host_frame, c->state, c->n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MI355_OK;
+}
+
+void *mi355_state_device_ptr(mi355_core *c) { return c ? c->state : nullptr; }
+
+int mi355_set_conv_kernel(mi355_core *c, const float *k9) {
+    if (!c || !k9) return fail(MI355_ERR_INVALID, "null argument");
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->k9, k9, 9 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_k9 = true;
+    return MI355_OK;
+}
+
+int mi355_set_glyphs(mi355_core *c, const uint8_t *chars_px, int nglyphs, int glyph_h, int glyph_w,
+                     const char *charset) {
+    if (!c || !chars_px || !charset) return fail(MI355_ERR_INVALID, "null argument");
+    if (nglyphs < 0 || glyph_h < 0 || glyph_w < 0 || (int)strlen(charset) != nglyphs)
+        return fail(MI355_ERR_INVALID, "glyph atlas / charset mismatch");
+    if (int rc = use_device(c)) return rc;
+    const size_t bytes = (size_t)nglyphs * 3 * glyph_h * glyph_w;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->glyphs) { (void)hipFree(c->glyphs); c->glyphs = nullptr; }
+    HIP_TRY(hipMalloc((void **)&c->glyphs, bytes ? bytes : 16));
+    HIP_TRY(hipMemcpy(c->glyphs, chars_px, bytes, hipMemcpyHostToDevice));
+    c->nglyphs = nglyphs; c->glyph_h = glyph_h; c->glyph_w = glyph_w;
+    c->charset = charset;
+    return MI355_OK;
+}
+
+int mi355_diff_stream_batch(mi355_core *c, const void *d_frames, size_t stride_bytes, int nframes,
+                            void *d_offsets, void *d_xs, void *d_diff, size_t capacity) {
+    return run_batch(c, false, d_frames, nullptr, stride_bytes, nframes, d_offsets, d_xs, d_diff, capacity);
+}
+
+int mi355_diff_pairs_batch(mi355_core *c, const void *d_cur, const void *d_prev, size_t stride_bytes,
+                           int nframes, void *d_offsets, void *d_xs, void *d_diff, size_t capacity) {
+    return run_batch(c, true, d_cur, d_prev, stride_bytes, nframes, d_offsets, d_xs, d_diff, capacity);
+}
+
+int mi355_int_diff(mi355_core *c, const void *d_cur, const void *d_prev, void *d_out, size_t n) {
+    if (!c || (n && (!d_cur || !d_prev || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(launch_int_diff((const int32_t *)d_cur, (const int32_t *)d_prev, (int32_t *)d_out, n, c->stream));
+    return MI355_OK;
+}
+
+int mi355_gray_avg(mi355_core *c, const void *d_in, void *d_out) {
+    if (!c || (c->n && (!d_in || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(launch_gray((const uint8_t *)d_in, (uint8_t *)d_out, c->n / 3, false, c->stream));
+    return MI355_OK;
+}
+
+int mi355_gray_weighted(mi355_core *c, const void *d_in, void *d_out) {
+    if (!c || (c->n && (!d_in || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(launch_gray((const uint8_t *)d_in, (uint8_t *)d_out, c->n / 3, true, c->stream));
+    return MI355_OK;
+}
+
+int mi355_binarize_chain(mi355_core *c, const void *d_gray, void *d_out, void *d_hist, void *d_thr) {
+    if (!c || (c->n && (!d_gray || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
+    if (int rc = use_device(c)) return rc;
+    int32_t *hist = d_hist ? (int32_t *)d_hist : c->hist;
+    int32_t *thr = d_thr ? (int32_t *)d_thr : c->thr;
+    HIP_TRY(launch_binarize_chain((const uint8_t *)d_gray, (uint8_t *)d_out, c->n, hist, thr, c->stream));
+    return MI355_OK;
+}
+
+int mi355_heat_map(mi355_core *c, const void *d_cur, const void *d_prev, void *d_out) {
+    if (!c || (c->n && (!d_cur || !d_prev || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(launch_heat_map((const uint8_t *)d_cur, (const uint8_t *)d_prev, (uint8_t *)d_out, c->n / 3,
+                            c->lut, c->stream));
+    return MI355_OK;
+}
+
+int mi355_red_dense(mi355_core *c, const void *d_cur, const void *d_prev, void *d_out) {
+    if (!c || (c->n && (!d_cur || !d_prev || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(launch_red_dense((const uint8_t *)d_cur, (const uint8_t *)d_prev, (uint8_t *)d_out, c->n / 3,
+                             c->cfg.threshold, c->stream));
+    return MI355_OK;
+}
+
+int mi355_red_overlap(mi355_core *c, void *d_img, const void *d_xs, const void *d_count, uint32_t count) {
+    if (!c || !d_img || ((d_count || count) && !d_xs)) return fail(MI355_ERR_INVALID, "null argument");
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(launch_red_overlap((uint8_t *)d_img, (const int32_t *)d_xs, (const uint32_t *)d_count, count,
+                               c->n, c->stream));
+    return MI355_OK;
+}
+
+int mi355_conv3x3(mi355_core *c, const void *d_in, void *d_out) {
+    if (!c || (c->n && (!d_in || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
+    if (d_in == d_out && c->n) return fail(MI355_ERR_INVALID, "conv3x3 cannot run in place");
+    if (!c->have_k9) return fail(MI355_ERR_STATE, "mi355_set_conv_kernel not called");
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(launch_conv3x3((const uint8_t *)d_in, (uint8_t *)d_out, c->cfg.width, c->cfg.height, c->k9,
+                           c->stream));
+    return MI355_OK;
+}
+
+// CUDACore::exec_core, kernels.cu:430-525.
+int mi355_exec(mi355_core *c, uint8_t *frame_data, uint8_t *show_ready, const char *text,
+               uint32_t *h_pos, int32_t *h_xs) {
+    if (!c || !frame_data || !h_pos || !h_xs) return fail(MI355_ERR_INVALID, "null argument");
+    const int vis = c->cfg.visualizer;
+    if (vis != MI355_VIS_NONE && !show_ready) return fail(MI355_ERR_INVALID, "visualizer set but show_ready is null");
+    if (c->cfg.noise_filter && !c->have_k9) return fail(MI355_ERR_STATE, "noise filter on but no conv kernel set");
+    if (int rc = use_device(c)) return rc;
+    hipStream_t s = c->stream;
+    const uint32_t N = c->n, npix = N / 3;
+
+    // kernels.cu:457-462  H2D (+ convolution when NOISE_FILTER)
+    if (c->cfg.noise_filter) {
+        HIP_TRY(hipMemcpyAsync(c->aux, frame_data, N, hipMemcpyHostToDevice, s));
+        HIP_TRY(launch_conv3x3(c->aux, c->in, c->cfg.width, c->cfg.height, c->k9, s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->in, frame_data, N, hipMemcpyHostToDevice, s));
+    }
+    // kernels.cu:466-476  text overlay, one glyph per character
+    if (text && c->glyphs) {
+        const size_t full_area = (size_t)3 * c->glyph_h * c->glyph_w;
+        int offset = 0;
+        for (const char *p = text; *p; ++p, offset += c->glyph_w * 3) {
+            const size_t idx = c->charset.find(*p);
+            if (idx == std::string::npos) continue;
+            HIP_TRY(launch_blit_glyph(c->in, c->glyphs + idx * full_area, c->glyph_h, 3 * c->glyph_w, offset,
+                                      3 * c->cfg.width, c->cfg.height, s));
+        }
+    }
+    // kernels.cu:478-502  visualisers that look at the frame before the diff
+    if (vis == MI355_VIS_HEAT) {
+        HIP_TRY(launch_heat_map(c->in, c->state, c->vis, npix, c->lut, s));
+    } else if (vis == MI355_VIS_GRAY) {
+        HIP_TRY(launch_gray(c->in, c->vis, npix, true, s));
+    } else if (vis == MI355_VIS_BINARIZE) {
+        HIP_TRY(launch_gray(c->in, c->aux, npix, true, s));
+        HIP_TRY(launch_binarize_chain(c->aux, c->vis, N, c->hist, c->thr, s));
+    } else if (vis == MI355_VIS_RED_OVERLAP) {
+        // kernels.cu:517 paints onto d_previous, i.e. the state *before* this frame's feedback
+        HIP_TRY(hipMemcpyAsync(c->vis, c->state, N, hipMemcpyDeviceToDevice, s));
+    } else if (vis == MI355_VIS_RED) {
+        HIP_TRY(hipMemsetAsync(c->vis, 0, N, s));                      // kernels.cu:513
+    }
+    if (vis == MI355_VIS_HEAT || vis == MI355_VIS_GRAY || vis == MI355_VIS_BINARIZE)
+        HIP_TRY(hipMemcpyAsync(show_ready, c->vis, N, hipMemcpyDeviceToHost, s));
+
+    // kernels.cu:505  kernel2
+    if (int rc = run_batch(c, false, c->in, nullptr, N, 1, c->offsets, c->one_xs, c->one_diff, N)) return rc;
+    // kernels.cu:507-508  count back + first synchronisation
+    HIP_TRY(hipMemcpyAsync(c->h_count, c->offsets, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t pos = c->h_count[1];
+    *h_pos = pos;
+    // kernels.cu:511-520  red maps from the packed indices
+    if (vis == MI355_VIS_RED || vis == MI355_VIS_RED_OVERLAP) {
+        HIP_TRY(launch_red_overlap(c->vis, c->one_xs, nullptr, pos, N, s));
+        HIP_TRY(hipMemcpyAsync(show_ready, c->vis, N, hipMemcpyDeviceToHost, s));
+    }
+    // kernels.cu:522-524
+    if (pos) {
+        HIP_TRY(hipMemcpyAsync(frame_data, c->one_diff, pos, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h_xs, c->one_xs, (size_t)pos * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return MI355_OK;
+}
+
+int mi355_host_alloc(void **out, size_t bytes) {
+    if (!out) return fail(MI355_ERR_INVALID, "null argument");
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
+    return MI355_OK;
+}
+
+int mi355_host_free(void *p) {
+    if (!p) return MI355_OK;
+    HIP_TRY(hipHostFree(p));
+    return MI355_OK;
+}
+
+int mi355_set_timing(mi355_core *c, int enabled) {
+    if (!c) return fail(MI355_ERR_INVALID, "null core");
+    if (int rc = use_device(c)) return rc;
+    if (int rc = harvest_timing(c)) return rc;
+    c->timing = enabled != 0;
+    return MI355_OK;
+}
+
+int mi355_get_timing(mi355_core *c, double *ms_pack, double *ms_total, int *launches) {
+    if (!c) return fail(MI355_ERR_INVALID, "null core");
+    if (int rc = use_device(c)) return rc;
+    if (int rc = harvest_timing(c)) return rc;
+    if (ms_pack) *ms_pack = c->ms_pack;
+    if (ms_total) *ms_total = c->ms_total;
+    if (launches) *launches = c->launches;
+    return MI355_OK;
+}
+
+int mi355_reset_timing(mi355_core *c) {
+    if (!c) return fail(MI355_ERR_INVALID, "null core");
+    if (int rc = use_device(c)) return rc;
+    if (int rc = harvest_timing(c)) return rc;
+    c->ms_pack = c->ms_total = 0;
+    c->launches = 0;
+    return MI355_OK;
+}
+
+}  // extern "C"

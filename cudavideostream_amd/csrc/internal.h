@@ -1,0 +1,71 @@
+// internal.h -- shared declarations of libmi355diff (not part of the C-ABI).
+#ifndef MI355_INTERNAL_H_
+#define MI355_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace mi355 {
+
+// Geometry of the diff/threshold/pack kernel: one wave64 owns one 1 KiB *tile* of the frame
+// (64 lanes x 16 B, a single global_load_dwordx4 per frame) for the whole batch.
+constexpr uint32_t kTileBytes = 1024;
+constexpr uint32_t kWavesPerBlock = 4;
+constexpr uint32_t kGatherTiles = 64;  // tiles per gather workgroup
+
+struct PackArgs {
+    const uint8_t *cur;    // frame t at cur + t*stride
+    const uint8_t *prev;   // pair mode: prev frame t at prev + t*stride; stream mode: unused
+    uint8_t *state;        // stream mode: N bytes, read at start and written back at the end
+    size_t stride;         // bytes between frames
+    uint32_t n;            // bytes per frame
+    int32_t nframes;       // T
+    int32_t thr;           // threshold
+    uint32_t ntiles;       // ceil(n / 1024)
+    uint32_t log_cap;      // entries of log per tile (>= 1024 * T)
+    int32_t *log_xs;       // [ntiles][log_cap]
+    uint8_t *log_diff;     // [ntiles][log_cap]
+    uint32_t *cnt;         // [T][ntiles]  flagged bytes of (frame, tile)
+    uint32_t *logpos;      // [T][ntiles]  position of that segment inside the tile's log
+};
+
+struct GatherArgs {
+    const int32_t *log_xs;
+    const uint8_t *log_diff;
+    const uint32_t *cnt;      // [T][ntiles]
+    const uint32_t *logpos;   // [T][ntiles]
+    const uint32_t *segoff;   // [T][ntiles]  exclusive scan of cnt over tiles, per frame
+    const uint32_t *offsets;  // [T+1]        exclusive scan of the frame totals
+    uint32_t ntiles;
+    uint32_t log_cap;
+    int32_t *out_xs;
+    uint8_t *out_diff;
+    size_t capacity;
+};
+
+// diff_pack.hip
+hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, hipStream_t s);
+hipError_t launch_scan(const uint32_t *cnt, uint32_t *segoff, uint32_t *totals, uint32_t ntiles,
+                       int nframes, uint32_t *offsets, hipStream_t s);
+hipError_t launch_gather(const GatherArgs &a, int nframes, hipStream_t s);
+
+// filters.hip
+hipError_t launch_int_diff(const int32_t *cur, const int32_t *prev, int32_t *out, size_t n,
+                           hipStream_t s);
+hipError_t launch_gray(const uint8_t *in, uint8_t *out, uint32_t npix, bool weighted, hipStream_t s);
+hipError_t launch_binarize_chain(const uint8_t *gray, uint8_t *out, uint32_t nbytes, int32_t *hist,
+                                 int32_t *thr, hipStream_t s);
+hipError_t launch_heat_map(const uint8_t *cur, const uint8_t *prev, uint8_t *out, uint32_t npix,
+                           const uint8_t *lut, hipStream_t s);
+hipError_t launch_red_dense(const uint8_t *cur, const uint8_t *prev, uint8_t *out, uint32_t npix,
+                            int thr, hipStream_t s);
+hipError_t launch_red_overlap(uint8_t *img, const int32_t *xs, const uint32_t *d_count,
+                              uint32_t count, uint32_t nbytes, hipStream_t s);
+hipError_t launch_conv3x3(const uint8_t *in, uint8_t *out, int w, int h, const float *k9,
+                          hipStream_t s);
+hipError_t launch_blit_glyph(uint8_t *frame, const uint8_t *glyph, int glyph_h, int glyph_wbytes,
+                             int x_off_bytes, int frame_wbytes, int frame_h, hipStream_t s);
+
+}  // namespace mi355
+#endif

@@ -1,0 +1,71 @@
+"""Multi-GPU exchange step: gather-v of the changed-pixel streams to one rank.
+
+The reference has no multi-GPU code; its only "exchange" is the sender thread
+that writes {u32 n, i32 xs[n], u8 diff[n]} per frame to one socket (server/src/threads.cpp:223-233).
+With one process per GPU, every rank runs an independent stream (or an independent set of frame
+pairs) and the diff/threshold/pack path needs NO collective; the single exchange is this gather of
+the per-frame index (offsets) and, where a single consumer wants it, of the payload.
+
+Collectives are torch.distributed calls: backend "nccl" is RCCL over xGMI on the GPU box, "gloo" in
+the CPU tests.  The payload moves as grouped point-to-point sends/receives (one per peer, all
+concurrent: 7 direct xGMI links into the root), not as a ring collective.
+"""
+import torch
+import torch.distributed as dist
+
+
+def gather_index(offsets, dst=0):
+    """offsets: uint32-as-int32 [B+1] exclusive scan of one rank's per-frame counts.
+    Returns on dst an int32 tensor [world, B+1]; None elsewhere."""
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    if world == 1:
+        return offsets.unsqueeze(0)
+    if rank == dst:
+        out = torch.empty((world,) + tuple(offsets.shape), dtype=offsets.dtype, device=offsets.device)
+        parts = list(out.unbind(0))
+        dist.gather(offsets, parts, dst=dst)
+        return out
+    dist.gather(offsets, None, dst=dst)
+    return None
+
+
+def gather_payload(offsets, xs, diff, dst=0):
+    """Gather-v of (xs[:total], diff[:total]) of every rank to dst, concatenated in rank order.
+
+    Returns on dst (totals[world] (python ints), xs_all, diff_all, index[world, B+1]); on other ranks
+    (totals, None, None, None).  Synchronises the host once to learn the local total (the reference
+    also reads its count back before the copies, kernels.cu:507-508)."""
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    total = int(offsets[-1].item()) & 0xFFFFFFFF
+    if world == 1:
+        return [total], xs[:total], diff[:total], offsets.unsqueeze(0)
+    t_local = torch.tensor([total], dtype=torch.int64, device=offsets.device)
+    t_all = [torch.zeros_like(t_local) for _ in range(world)]
+    dist.all_gather(t_all, t_local)
+    totals = [int(t.item()) for t in t_all]
+    index = gather_index(offsets, dst)
+    if rank == dst:
+        n_all = sum(totals)
+        xs_all = torch.empty(max(n_all, 1), dtype=xs.dtype, device=xs.device)
+        df_all = torch.empty(max(n_all, 1), dtype=diff.dtype, device=diff.device)
+        ops, at = [], 0
+        for r in range(world):
+            c = totals[r]
+            if r == dst:
+                xs_all[at:at + c] = xs[:c]
+                df_all[at:at + c] = diff[:c]
+            elif c:
+                ops.append(dist.P2POp(dist.irecv, xs_all[at:at + c], r))
+                ops.append(dist.P2POp(dist.irecv, df_all[at:at + c], r))
+            at += c
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return totals, xs_all[:n_all], df_all[:n_all], index
+    if total:
+        ops = [dist.P2POp(dist.isend, xs[:total], dst), dist.P2POp(dist.isend, diff[:total], dst)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return totals, None, None, None

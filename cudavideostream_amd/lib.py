@@ -1,0 +1,104 @@
+"""ctypes view of libmi355diff.so -- the C-ABI declared in include/mi355diff.h.
+
+The library is built in-tree (cudavideostream_amd/libmi355diff.so) by `make -C cudavideostream_amd/csrc`
+or `__graft_entry__.build()`.  There is no fallback: if the shared object is missing or cannot be
+loaded, importing a symbol from here raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355diff.so")
+
+OK = 0
+ERR_INVALID = -1
+ERR_HIP = -2
+ERR_STATE = -3
+
+VIS_NONE, VIS_HEAT, VIS_RED, VIS_RED_OVERLAP, VIS_GRAY, VIS_BINARIZE = range(6)
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("threshold", C.c_int32),
+        ("max_batch", C.c_int32),
+        ("device", C.c_int32),
+        ("noise_filter", C.c_int32),
+        ("visualizer", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/mi355diff.h declares
+SYMBOLS = {
+    "mi355_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "mi355_destroy": (None, [C.c_void_p]),
+    "mi355_last_error": (C.c_char_p, []),
+    "mi355_frame_bytes": (C.c_size_t, [C.c_void_p]),
+    "mi355_workspace_bytes": (C.c_size_t, [C.c_void_p]),
+    "mi355_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi355_synchronize": (C.c_int, [C.c_void_p]),
+    "mi355_set_state": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi355_get_state": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi355_state_device_ptr": (C.c_void_p, [C.c_void_p]),
+    "mi355_set_conv_kernel": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi355_set_glyphs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p]),
+    "mi355_diff_stream_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi355_diff_pairs_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi355_int_diff": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi355_gray_avg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355_gray_weighted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355_binarize_chain": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355_heat_map": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355_red_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355_red_overlap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "mi355_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355_exec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]),
+    "mi355_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "mi355_host_free": (C.c_int, [C.c_void_p]),
+    "mi355_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "mi355_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_int)]),
+    "mi355_reset_timing": (C.c_int, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def build():
+    """Compile libmi355diff.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-s"], check=True)
+
+
+def load():
+    """Load the shared library and bind every declared symbol.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `make -C cudavideostream_amd/csrc` "
+            "(there is no non-HIP fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class Mi355Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmi355diff error {code}: {msg}")
+        self.code = code
+
+
+def check(rc):
+    if rc != OK:
+        raise Mi355Error(rc, load().mi355_last_error().decode(errors="replace"))

@@ -1,0 +1,153 @@
+/*
+ * mi355diff.h -- C-ABI of libmi355diff.so: the MI355X (gfx950) frame-differencing + filter core.
+ *
+ * This is the drop-in boundary for the hot path of MatteoBattilana/CUDAVideoStream: everything the
+ * reference's `diff::cuda::CUDACore` (server/include/kernels.cuh:13-43, server/src/kernels.cu:377-536)
+ * does on the GPU, behind plain C entry points (no C++/STL/torch types).  The C++ class of the same
+ * name that the reference's server.cpp links against lives in cudavideostream_amd/compat/ and only
+ * forwards to these functions; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - A frame is width*height BGR24 pixels, row-major, N = 3*width*height bytes
+ *     (server/src/server.cpp:46).  All arithmetic is per byte, as in the reference.
+ *   - "d_" arguments are device (HBM) pointers of the core's device; everything else is host memory.
+ *   - One core = one device = one stream = one caller thread at a time (the reference calls exec_core
+ *     from a single thread, server/src/server.cpp:139).  Several cores (one per GPU) are independent.
+ *   - Every function returns MI355_OK (0) or a negative error; mi355_last_error() gives the text for
+ *     the calling thread.  Device-resident entry points are asynchronous on the core's stream and
+ *     never synchronise; host-buffer entry points return after the results are in the host buffers.
+ *   - There is no CPU fallback: without a usable HIP device mi355_create() fails.
+ */
+#ifndef MI355DIFF_H_
+#define MI355DIFF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_OK 0
+#define MI355_ERR_INVALID (-1)  /* bad argument / configuration */
+#define MI355_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define MI355_ERR_STATE (-3)    /* call not valid in the core's current state */
+
+/* Visualiser selection of exec(): the values of NOISE_VISUALIZER in server/include/common.h:11. */
+#define MI355_VIS_NONE 0
+#define MI355_VIS_HEAT 1         /* kernels.cu:480  heat_map                      */
+#define MI355_VIS_RED 2          /* kernels.cu:513  memset + red_black_map_overlap */
+#define MI355_VIS_RED_OVERLAP 3  /* kernels.cu:517  red on the previous frame      */
+#define MI355_VIS_GRAY 4         /* kernels.cu:487  grayscale_kernel_v3 (weighted) */
+#define MI355_VIS_BINARIZE 5     /* kernels.cu:493-498 gray + histogram + max + binarize */
+
+typedef struct mi355_core mi355_core;
+
+typedef struct mi355_config {
+    int32_t width;      /* pixels */
+    int32_t height;     /* pixels */
+    int32_t threshold;  /* LR_THRESHOLDS, server/include/common.h:14 (20); strict >, 0..127 */
+    int32_t max_batch;  /* largest nframes of a *_batch call; sizes the workspace (>= 1) */
+    int32_t device;     /* HIP device ordinal, or -1 for the current device */
+    int32_t noise_filter; /* != 0: exec() runs the 3x3 convolution first (NOISE_FILTER, common.h:5) */
+    int32_t visualizer; /* MI355_VIS_* used by exec() (NOISE_VISUALIZER, common.h:11) */
+    int32_t reserved;
+} mi355_config;
+
+/* ---- life cycle: CUDACore::CUDACore (kernels.cu:377-428) without the uploads ------------------ */
+int mi355_create(const mi355_config *cfg, mi355_core **out);
+void mi355_destroy(mi355_core *core);
+const char *mi355_last_error(void);
+/* Size in bytes of one frame (3*width*height). */
+size_t mi355_frame_bytes(const mi355_core *core);
+/* Bytes of HBM workspace held by the core (state, logs, counters). */
+size_t mi355_workspace_bytes(const mi355_core *core);
+
+/* Use an existing hipStream_t (e.g. PyTorch's current stream) instead of the core's own stream;
+ * NULL restores the core's stream. */
+int mi355_set_stream(mi355_core *core, void *hip_stream);
+int mi355_synchronize(mi355_core *core);
+
+/* ---- state: the reconstructed client frame ("previous" with negative feedback) ------------------
+ * kernels.cu:406 uploads the base frame into d_current; after each frame the surviving buffer is
+ * cur where |df| > threshold and prev elsewhere (kernels.cu:312-331, tests/cuda_streaming/test.cu:571).
+ * The core keeps ONE persistent state buffer with exactly those contents. */
+int mi355_set_state(mi355_core *core, const uint8_t *host_frame);
+int mi355_get_state(mi355_core *core, uint8_t *host_frame);
+void *mi355_state_device_ptr(mi355_core *core);
+
+/* ---- constants: cudaMemcpyToSymbol(dev_k) kernels.cu:394, glyph upload kernels.cu:381-382 ------ */
+int mi355_set_conv_kernel(mi355_core *core, const float *k9);
+int mi355_set_glyphs(mi355_core *core, const uint8_t *chars_px, int nglyphs, int glyph_h, int glyph_w,
+                     const char *charset);
+
+/* ---- the hot path, device resident ---------------------------------------------------------------
+ * kernel2 (kernels.cu:289-334) over a batch.  For every frame t (in order) and every byte i
+ * (ascending): df = frame[t][i] - state[i]; if |df| > threshold emit (xs = i, diff = (uint8)df) and
+ * state[i] = frame[t][i].  Output is the CPU path's order (tests/cuda_streaming/test.cu:563-573),
+ * not the reference kernel's atomicInc order.
+ *   d_frames : nframes frames, frame t at d_frames + t*stride_bytes (stride_bytes >= N; the fast
+ *              path needs d_frames and stride_bytes to be multiples of 16)
+ *   d_offsets: uint32[nframes+1], exclusive scan of the per-frame counts (offsets[0] = 0)
+ *   d_xs     : int32[capacity]  byte indices, frame t's entries at [offsets[t], offsets[t+1])
+ *   d_diff   : uint8[capacity]  (uint8)df of the same entries
+ * Entries beyond `capacity` are dropped (offsets stay exact), so check offsets[nframes] <= capacity.
+ * Asynchronous on the core's stream. */
+int mi355_diff_stream_batch(mi355_core *core, const void *d_frames, size_t stride_bytes, int nframes,
+                            void *d_offsets, void *d_xs, void *d_diff, size_t capacity);
+
+/* Stateless form (tests/algorithms_benchmarks.cu style frame pairs): frame t is compared with
+ * d_prev + t*stride_bytes instead of the state; the core's state is neither read nor written. */
+int mi355_diff_pairs_batch(mi355_core *core, const void *d_cur, const void *d_prev,
+                           size_t stride_bytes, int nframes, void *d_offsets, void *d_xs,
+                           void *d_diff, size_t capacity);
+
+/* Integer difference of tests/algorithms_benchmarks.cu:24-30 (kernel1): d[i] = cur[i] - prev[i] on
+ * int32 arrays of n elements, no threshold, no pack. */
+int mi355_int_diff(mi355_core *core, const void *d_cur, const void *d_prev, void *d_out, size_t n);
+
+/* ---- filters, device resident (all N-byte BGR24 frames; in-place allowed unless noted) --------- */
+/* kernels.cu:31-43 / server.cpp:96-101: s = (B+G+R)/3 into the 3 channels. */
+int mi355_gray_avg(mi355_core *core, const void *d_in, void *d_out);
+/* kernels.cu:67-95 / tests/grayscale-weighted/cpu.cu:40: (uint8)(0.114*B + 0.587*G + 0.299*R). */
+int mi355_gray_weighted(mi355_core *core, const void *d_in, void *d_out);
+/* kernels.cu:138-241 / server.cpp:103-135: histogram of every 3rd byte, two-max threshold clamped
+ * to [50,200] (CPU semantics), binarize.  d_hist (int32[256]) and d_thr (int32[1]) may be NULL. */
+int mi355_binarize_chain(mi355_core *core, const void *d_gray, void *d_out, void *d_hist, void *d_thr);
+/* kernels.cu:243-270 / tests/heat_map_benchmark/cpu.cu:19-27,54-66. */
+int mi355_heat_map(mi355_core *core, const void *d_cur, const void *d_prev, void *d_out);
+/* tests/heat_map_red_benchmark/cpu.cu:38-55 (dense red/black map). */
+int mi355_red_dense(mi355_core *core, const void *d_cur, const void *d_prev, void *d_out);
+/* kernels.cu:273-281: img[x + (2 - x%3)] = 255 for the n indices in d_xs; n is read from d_count
+ * (uint32 on the device) when d_count != NULL, else `count` is used. */
+int mi355_red_overlap(mi355_core *core, void *d_img, const void *d_xs, const void *d_count,
+                      uint32_t count);
+/* kernels.cu:97-136: 3x3 convolution with the kernel of mi355_set_conv_kernel; not in-place. */
+int mi355_conv3x3(mi355_core *core, const void *d_in, void *d_out);
+
+/* ---- the per-frame host entry point: CUDACore::exec_core (kernels.cu:430-525) -------------------
+ * frame_data: in = the captured frame (N bytes), out = diff[0..*h_pos)      (kernels.cu:461,522)
+ * show_ready: out = the visualisation frame when cfg.visualizer != 0        (kernels.cu:481-518)
+ * text      : overlay string (characters of the glyph charset) or NULL      (kernels.cu:466-476)
+ * h_pos     : out = number of changed bytes                                 (kernels.cu:507)
+ * h_xs      : out = their byte indices, ascending                           (kernels.cu:523)
+ * Returns after both device synchronisations of the reference (kernels.cu:508,524). */
+int mi355_exec(mi355_core *core, uint8_t *frame_data, uint8_t *show_ready, const char *text,
+               uint32_t *h_pos, int32_t *h_xs);
+
+/* ---- pinned host memory: CUDACore::alloc_arrays (kernels.cu:531-536) ---------------------------- */
+int mi355_host_alloc(void **out, size_t bytes);
+int mi355_host_free(void *p);
+
+/* ---- measurement ---------------------------------------------------------------------------------
+ * With timing on, every *_batch call brackets its kernels with HIP events on the stream they are
+ * launched on.  mi355_get_timing synchronises the stream and returns the sums since the last reset:
+ * ms_pack = the diff/threshold/pack kernel alone, ms_total = pack + scan + gather. */
+int mi355_set_timing(mi355_core *core, int enabled);
+int mi355_get_timing(mi355_core *core, double *ms_pack, double *ms_total, int *launches);
+int mi355_reset_timing(mi355_core *core);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355DIFF_H_ */

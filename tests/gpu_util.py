@@ -1,0 +1,41 @@
+"""Helpers for the `-m gpu` parity tests: every call goes through the C-ABI (libmi355diff.so)."""
+import numpy as np
+import torch
+
+from cudavideostream_amd import CUDACore
+
+DEV = "cuda:0"
+
+
+def to_dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def run_stream(core, frames, capacity=None, stride=None, pair_prev=None):
+    """frames: (T, N) uint8 numpy or cuda tensor.  Returns (offsets, xs, diff) as numpy, with xs/diff
+    cut to min(total, capacity)."""
+    d_frames = frames if torch.is_tensor(frames) else to_dev(frames)
+    T = d_frames.shape[0]
+    n = core.total
+    cap = T * n if capacity is None else capacity
+    d_off = torch.full((T + 1,), 0xFFFFFFFF, dtype=torch.int64, device=DEV).to(torch.int32)
+    d_xs = torch.full((max(cap, 1),), -7, dtype=torch.int32, device=DEV)
+    d_df = torch.full((max(cap, 1),), 0xA5, dtype=torch.uint8, device=DEV)
+    if pair_prev is None:
+        core.diff_stream_batch(d_frames, T, d_off, d_xs, d_df, cap, stride=stride)
+    else:
+        d_prev = pair_prev if torch.is_tensor(pair_prev) else to_dev(pair_prev)
+        core.diff_pairs_batch(d_frames, d_prev, T, d_off, d_xs, d_df, cap, stride=stride)
+    core.synchronize()
+    off = d_off.cpu().numpy().view(np.uint32)
+    tot = min(int(off[-1]), cap)
+    return off, d_xs[:tot].cpu().numpy(), d_df[:tot].cpu().numpy(), (d_xs, d_df)
+
+
+def oracle_pairs(po, cur, prev, thr=20):
+    offs, xs, df = [0], [], []
+    for t in range(cur.shape[0]):
+        c, x, d, _ = po.diff_pack(cur[t], prev[t], thr)
+        offs.append(offs[-1] + c); xs.append(x); df.append(d)
+    return (np.array(offs, np.uint32), np.concatenate(xs) if xs else np.empty(0, np.int32),
+            np.concatenate(df) if df else np.empty(0, np.uint8))

@@ -1,0 +1,239 @@
+"""GPU parity of K1 (diff + threshold + negative feedback + ordered pack) against the CPU oracle
+(tests/cuda_streaming/test.cu:560-576 restated), bit-exact, through the C-ABI."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from cudavideostream_amd import CUDACore, lib, synth
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from gpu_util import DEV, oracle_pairs, run_stream, to_dev  # noqa: E402
+
+
+def check_stream(po, core, base, frames, thr=20, **kw):
+    core.set_state(base)
+    off, xs, df, _ = run_stream(core, frames, **kw)
+    eo, exs, edf, est = po.diff_stream(np.asarray(frames), base, thr)
+    assert np.array_equal(off, eo), (off, eo)
+    assert np.array_equal(xs, exs)
+    assert np.array_equal(df, edf)
+    assert np.array_equal(core.get_state(), est)
+    return off
+
+
+def test_golden_stream_64x48(po):
+    g = golden("oracle_diff_stream_64x48.npz")
+    with CUDACore(64, 48, max_batch=8) as core:
+        core.set_state(g["base"])
+        off, xs, df, _ = run_stream(core, g["frames"])
+        assert np.array_equal(off, g["offsets"]) and np.array_equal(xs, g["xs"])
+        assert np.array_equal(df, g["diff"]) and np.array_equal(core.get_state(), g["state"])
+
+
+def test_edge_strip_every_byte_pair(po):
+    """All 65536 (prev, cur) pairs, three times (N = 3*256*256): |df| = 20 / 21, wrap-around."""
+    cur, prev = synth.edge_strip(3)
+    with CUDACore(256, 256, max_batch=1) as core:
+        off = check_stream(po, core, prev, cur[None, :])
+        assert off[1] == 3 * int(golden("oracle_diff_edge_strip.npz")["count"])
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 4, 5, 7, 8, 9, 13])
+def test_batch_lengths(po, T):
+    """Frame groups of 4 are double buffered: every tail length must work."""
+    base, frames = synth.webcam_stream(T, 80, 60, seed=T)
+    with CUDACore(80, 60, max_batch=13) as core:
+        check_stream(po, core, base, frames)
+
+
+def test_consecutive_batches_continue_the_stream(po):
+    base, frames = synth.webcam_stream(11, 96, 54, seed=3)
+    eo, exs, edf, est = po.diff_stream(frames, base)
+    with CUDACore(96, 54, max_batch=6) as core:
+        core.set_state(base)
+        o1, x1, d1, _ = run_stream(core, frames[:6])
+        o2, x2, d2, _ = run_stream(core, frames[6:])
+        assert np.array_equal(np.concatenate([x1, x2]), exs)
+        assert np.array_equal(np.concatenate([d1, d2]), edf)
+        assert np.array_equal(np.concatenate([o1, o2[1:] + o1[-1]]), eo)
+        assert np.array_equal(core.get_state(), est)
+
+
+@pytest.mark.parametrize("w,h", [(37, 11), (1, 1), (5, 1), (341, 1), (342, 1), (21, 17), (683, 3)])
+def test_ragged_sizes(po, w, h):
+    """N not a multiple of 16 / 1024: byte-wise tail path, partial last tile."""
+    rng = np.random.default_rng(w * 131 + h)
+    n = 3 * w * h
+    base = rng.integers(0, 256, n, dtype=np.uint8)
+    frames = np.clip(base.astype(int) + rng.integers(-40, 41, (3, n)), 0, 255).astype(np.uint8)
+    with CUDACore(w, h, max_batch=3) as core:
+        check_stream(po, core, base, frames)
+    if (w, h) == (37, 11):
+        g = golden("oracle_diff_ragged_37x11.npz")
+        with CUDACore(w, h, max_batch=1) as core:
+            off, xs, df, _ = run_stream(core, g["cur"][None, :], pair_prev=g["prev"][None, :])
+            assert off[1] == int(g["count"]) and np.array_equal(xs, g["xs"]) and np.array_equal(df, g["diff"])
+
+
+def test_static_flip_and_dense(po):
+    n = 3 * 128 * 64
+    with CUDACore(128, 64, max_batch=2) as core:
+        cur, prev = synth.static_pair(n)
+        assert check_stream(po, core, prev, cur[None, :])[1] == 0          # P = 0
+        cur, prev = synth.flip_pair(n)
+        assert check_stream(po, core, prev, cur[None, :])[1] == n          # P = N
+        a, b = synth.refrand_frame(n, 1), synth.refrand_frame(n, 2)        # S0, ~84.6 % flagged
+        off = check_stream(po, core, b, np.stack([a, b]))
+        assert 0.8 < off[1] / n < 0.9
+
+
+@pytest.mark.parametrize("thr", [0, 1, 20, 21, 127])
+def test_thresholds(po, thr):
+    cur, prev = synth.edge_strip(3)
+    with CUDACore(256, 256, threshold=thr, max_batch=1) as core:
+        check_stream(po, core, prev, cur[None, :], thr=thr)
+
+
+def test_pair_mode_refrand(po):
+    """tests/algorithms_benchmarks.cu style independent pairs; the core's state is untouched."""
+    n = 3 * 100 * 50
+    cur = np.stack([synth.refrand_frame(n, 10 + t) for t in range(5)])
+    prev = np.stack([synth.refrand_frame(n, 20 + t) for t in range(5)])
+    marker = synth.refrand_frame(n, 99)
+    with CUDACore(100, 50, max_batch=5) as core:
+        core.set_state(marker)
+        off, xs, df, _ = run_stream(core, cur, pair_prev=prev)
+        eo, exs, edf = oracle_pairs(po, cur, prev)
+        assert np.array_equal(off, eo) and np.array_equal(xs, exs) and np.array_equal(df, edf)
+        assert np.array_equal(core.get_state(), marker)
+
+
+def test_capacity_truncation_keeps_offsets_exact(po):
+    base, frames = synth.webcam_stream(4, 64, 48, seed=8)
+    eo, exs, edf, _ = po.diff_stream(frames, base)
+    cap = int(eo[2]) + 5  # cuts inside frame 2
+    with CUDACore(64, 48, max_batch=4) as core:
+        core.set_state(base)
+        off, xs, df, (d_xs, d_df) = run_stream(core, frames, capacity=cap)
+        assert np.array_equal(off, eo)
+        assert np.array_equal(xs, exs[:cap]) and np.array_equal(df, edf[:cap])
+
+
+def test_unaligned_stride_and_pointer(po):
+    """stride/pointer not multiples of 16 take the byte-load path and give the same answer."""
+    w, h = 64, 48
+    n = 3 * w * h
+    base, frames = synth.webcam_stream(3, w, h, seed=4)
+    stride = n + 5
+    buf = np.zeros(3 * stride + 3, np.uint8)
+    for t in range(3):
+        buf[3 + t * stride: 3 + t * stride + n] = frames[t]
+    d_buf = to_dev(buf)
+    eo, exs, edf, est = po.diff_stream(frames, base)
+    with CUDACore(w, h, max_batch=3) as core:
+        core.set_state(base)
+        d_off = torch.zeros(4, dtype=torch.int32, device=DEV)
+        d_xs = torch.zeros(3 * n, dtype=torch.int32, device=DEV)
+        d_df = torch.zeros(3 * n, dtype=torch.uint8, device=DEV)
+        core.diff_stream_batch(d_buf.data_ptr() + 3, 3, d_off, d_xs, d_df, 3 * n, stride=stride)
+        core.synchronize()
+        off = d_off.cpu().numpy().view(np.uint32)
+        assert np.array_equal(off, eo)
+        assert np.array_equal(d_xs[:off[-1]].cpu().numpy(), exs)
+        assert np.array_equal(d_df[:off[-1]].cpu().numpy(), edf)
+        assert np.array_equal(core.get_state(), est)
+
+
+def test_empty_frame_and_empty_batch():
+    with CUDACore(0, 0, max_batch=2) as core:
+        d_off = torch.full((3,), 9, dtype=torch.int32, device=DEV)
+        core.diff_stream_batch(None, 2, d_off, None, None, 0)
+        core.synchronize()
+        assert d_off.cpu().tolist() == [0, 0, 0]
+    with CUDACore(16, 16, max_batch=2) as core:
+        d_off = torch.full((1,), 9, dtype=torch.int32, device=DEV)
+        core.diff_stream_batch(None, 0, d_off, None, None, 0)
+        core.synchronize()
+        assert d_off.cpu().tolist() == [0]
+        with pytest.raises(lib.Mi355Error):
+            core.diff_stream_batch(d_off, 3, d_off, None, None, 0)   # nframes > max_batch
+
+
+def test_int_diff_benchmark_identity(po):
+    """tests/algorithms_benchmarks.cu: GPU diff checked by the reference's own checkDifference."""
+    h, w = 1920, 1080
+    n = h * w * 3
+    L = po.lib()
+    a = np.empty(n, np.int32); b = np.empty(n, np.int32)
+    L.ora_generate_image(a, h, w, 1)
+    L.ora_generate_image(b, h, w, 2)
+    with CUDACore(8, 8) as core:
+        d_a, d_b = to_dev(a), to_dev(b)
+        d_o = torch.empty_like(d_a)
+        core.int_diff(d_a, d_b, d_o, n)
+        core.synchronize()
+        out = d_o.cpu().numpy()
+        assert L.ora_check_difference(a, b, out, h, w) == 0
+        assert np.array_equal(out, a - b)
+        core.int_diff(d_a.data_ptr() + 4, d_b.data_ptr() + 4, d_o.data_ptr() + 4, 1001)  # unaligned, ragged
+        core.synchronize()
+        assert np.array_equal(d_o.cpu().numpy()[1:1002], (a - b)[1:1002])
+
+
+# ---- BASELINE.json sizes ------------------------------------------------------------------------------
+
+def test_1080p_stream_vs_oracle(po):
+    """config 2 at full size on a short batch the oracle finishes in seconds."""
+    W, H, T = 1920, 1080, 6
+    base, frames = synth.webcam_stream(T, W, H, device=DEV)
+    with CUDACore(W, H, max_batch=T) as core:
+        core.set_state(base.cpu().numpy())
+        off, xs, df, _ = run_stream(core, frames)
+        eo, exs, edf, est = po.diff_stream(frames.cpu().numpy(), base.cpu().numpy())
+        assert np.array_equal(off, eo) and np.array_equal(xs, exs) and np.array_equal(df, edf)
+        assert np.array_equal(core.get_state(), est)
+        p = np.diff(off.astype(np.int64))[1:] / (3 * W * H)
+        assert (0.01 < p).all() and (p < 0.06).all()
+
+
+def test_1080p_long_batch_properties():
+    """Full-size, 64-frame batch: size-independent properties instead of the (slow) oracle --
+    the client reconstruction (client/opencv.cpp:64-66) applied to the packed output rebuilds the
+    server state exactly, indices ascend strictly inside every frame, and the un-sent residual is
+    within the threshold of the true frame."""
+    W, H, T = 1920, 1080, 64
+    n = 3 * W * H
+    base, frames = synth.webcam_stream(T, W, H, device=DEV)
+    with CUDACore(W, H, max_batch=T) as core:
+        core.set_state(base.cpu().numpy())
+        cap = T * n // 8
+        d_off = torch.zeros(T + 1, dtype=torch.int32, device=DEV)
+        d_xs = torch.empty(cap, dtype=torch.int32, device=DEV)
+        d_df = torch.empty(cap, dtype=torch.uint8, device=DEV)
+        core.diff_stream_batch(frames, T, d_off, d_xs, d_df, cap)
+        core.synchronize()
+        off = d_off.cpu().numpy().view(np.uint32).astype(np.int64)
+        assert off[0] == 0 and (np.diff(off) > 0).all() and off[-1] <= cap
+        client = base.clone()
+        for t in range(T):
+            xs = d_xs[off[t]:off[t + 1]].long()
+            assert bool((xs[1:] > xs[:-1]).all()) and int(xs[0]) >= 0 and int(xs[-1]) < n
+            client[xs] += d_df[off[t]:off[t + 1]]          # uint8 wrap == client/opencv.cpp:65
+            resid = (client.to(torch.int16) - frames[t].to(torch.int16)).abs().max()
+            assert int(resid) <= 20
+        state = torch.from_numpy(core.get_state()).to(DEV)
+        assert bool((client == state).all())
+
+
+def test_4k_pair_vs_oracle(po):
+    """config 5 frame size (3840x2160), one S0-style dense pair and one sparse pair."""
+    W, H = 3840, 2160
+    n = 3 * W * H
+    cur = torch.stack([synth.refrand_frame(n, 1, device=DEV), synth.webcam_frame(1, W, H, device=DEV)])
+    prev = torch.stack([synth.refrand_frame(n, 2, device=DEV), synth.webcam_frame(0, W, H, device=DEV)])
+    with CUDACore(W, H, max_batch=2) as core:
+        off, xs, df, _ = run_stream(core, cur, pair_prev=prev)
+        eo, exs, edf = oracle_pairs(po, cur.cpu().numpy(), prev.cpu().numpy())
+        assert np.array_equal(off, eo) and np.array_equal(xs, exs) and np.array_equal(df, edf)

@@ -1,0 +1,222 @@
+"""GPU parity of the filter kernels (gray, binarize chain, heat map, red map, 3x3 noise filter) and of
+the per-frame host entry point exec_core, bit-exact against the CPU oracle and the fixtures recorded
+from the reference's own server.cpp CPU branch."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from cudavideostream_amd import CUDACore, lib, synth
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from gpu_util import DEV, to_dev  # noqa: E402
+
+
+def dev_out(n):
+    return torch.full((n,), 0x5A, dtype=torch.uint8, device=DEV)
+
+
+SIZES = [(64, 48), (37, 11), (1, 1), (17, 3), (200, 9), (1920, 8)]
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+def test_gray_heat_red(po, w, h):
+    rng = np.random.default_rng(w + h)
+    n = 3 * w * h
+    img = rng.integers(0, 256, n, dtype=np.uint8)
+    prv = np.clip(img.astype(int) + rng.integers(-60, 61, n), 0, 255).astype(np.uint8)
+    d_img, d_prv = to_dev(img), to_dev(prv)
+    with CUDACore(w, h) as core:
+        for fn, exp in ((core.gray_avg, po.gray_avg(img)), (core.gray_weighted, po.gray_weighted(img))):
+            d_o = dev_out(n)
+            fn(d_img, d_o); core.synchronize()
+            assert np.array_equal(d_o.cpu().numpy(), exp)
+        d_o = dev_out(n)
+        core.heat_map(d_img, d_prv, d_o); core.synchronize()
+        assert np.array_equal(d_o.cpu().numpy(), po.heat_map(img, prv))
+        d_o = dev_out(n)
+        core.red_dense(d_img, d_prv, d_o); core.synchronize()
+        assert np.array_equal(d_o.cpu().numpy(), po.red_dense(img, prv))
+        # in place + unaligned pointers
+        d_pad = torch.zeros(n + 1, dtype=torch.uint8, device=DEV)
+        d_pad[1:] = d_img
+        core.gray_avg(d_pad.data_ptr() + 1, d_pad.data_ptr() + 1); core.synchronize()
+        assert np.array_equal(d_pad[1:].cpu().numpy(), po.gray_avg(img))
+
+
+def test_gray_weighted_exhaustive_2_24(po):
+    """Every (B, G, R) triple against the double expression of tests/grayscale-weighted/cpu.cu:40."""
+    w, h = 4096, 4096
+    v = torch.arange(1 << 24, dtype=torch.int32, device=DEV)
+    bgr = torch.stack([v & 255, (v >> 8) & 255, v >> 16], dim=1).to(torch.uint8).reshape(-1)
+    with CUDACore(w, h) as core:
+        d_o = dev_out(bgr.numel())
+        core.gray_weighted(bgr, d_o); core.synchronize()
+        got = d_o.reshape(-1, 3)
+        assert bool((got[:, 0] == got[:, 1]).all()) and bool((got[:, 0] == got[:, 2]).all())
+        got = got[:, 0].cpu().numpy()
+    x = np.arange(1 << 24, dtype=np.int64)
+    exp = (0.114 * (x & 255).astype(np.float64) + 0.587 * ((x >> 8) & 255) + 0.299 * (x >> 16)).astype(np.uint8)
+    assert np.array_equal(got, exp)
+    s = golden("oracle_gray_weighted_sample.npz")
+    idx = s["bgr"][:, 0].astype(np.int64) | (s["bgr"][:, 1].astype(np.int64) << 8) | (s["bgr"][:, 2].astype(np.int64) << 16)
+    assert np.array_equal(got[idx], s["gray"])
+
+
+def test_binarize_chain_vs_reference_fixture(po):
+    """gray-avg + binarize chain == outputs recorded from the reference's server.cpp CPU branch."""
+    g = golden("ref_server_cpu_64x48.npz")
+    w, h = int(g["width"]), int(g["height"])
+    n = 3 * w * h
+    with CUDACore(w, h) as core:
+        d_hist = torch.zeros(256, dtype=torch.int32, device=DEV)
+        d_thr = torch.zeros(1, dtype=torch.int32, device=DEV)
+        for t in range(g["frames"].shape[0]):
+            d_in = to_dev(g["frames"][t])
+            d_gray, d_o = dev_out(n), dev_out(n)
+            core.gray_avg(d_in, d_gray)
+            core.binarize_chain(d_gray, d_o, d_hist, d_thr)
+            core.synchronize()
+            assert np.array_equal(d_o.cpu().numpy(), g["out"][t]), f"frame {t}"
+            gray = po.gray_avg(g["frames"][t])
+            assert np.array_equal(d_hist.cpu().numpy(), po.histogram(gray))
+            assert int(d_thr.item()) == po.two_max_threshold(po.histogram(gray))
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (37, 11), (1920, 1080)])
+def test_binarize_chain_weighted(po, w, h):
+    """config 3: weighted gray -> histogram -> two-max -> binarize."""
+    img = synth.webcam_frame(2, w, h, seed=6)
+    n = img.size
+    with CUDACore(w, h) as core:
+        d_gray, d_o = dev_out(n), dev_out(n)
+        core.gray_weighted(to_dev(img), d_gray)
+        core.binarize_chain(d_gray, d_o)
+        core.synchronize()
+        gw = po.gray_weighted(img)
+        assert np.array_equal(d_o.cpu().numpy(), po.binarize(gw, po.two_max_threshold(po.histogram(gw))))
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (3, 3), (1, 1), (65, 9), (130, 17), (1920, 1080)])
+def test_conv3x3(po, w, h):
+    rng = np.random.default_rng(w * 7 + h)
+    img = rng.integers(0, 256, 3 * w * h, dtype=np.uint8)
+    k = po.gaussian_kernel(3, 1.5)
+    with CUDACore(w, h, k=k) as core:
+        d_o = dev_out(img.size)
+        core.conv3x3(to_dev(img), d_o); core.synchronize()
+        assert np.array_equal(d_o.cpu().numpy(), po.conv3x3(img, w, h, k))
+    kk = rng.random(9).astype(np.float32)
+    kk /= kk.sum()   # mean-like kernel with awkward roundings
+    with CUDACore(w, h, k=kk) as core:
+        d_o = dev_out(img.size)
+        core.conv3x3(to_dev(img), d_o); core.synchronize()
+        assert np.array_equal(d_o.cpu().numpy(), po.conv3x3(img, w, h, kk))
+
+
+def test_conv_requires_kernel_and_out_of_place():
+    with CUDACore(8, 8) as core:
+        d = dev_out(192)
+        with pytest.raises(lib.Mi355Error):
+            core.conv3x3(d, dev_out(192))
+    with CUDACore(8, 8, k=np.ones(9, np.float32) / 9) as core:
+        d = dev_out(192)
+        with pytest.raises(lib.Mi355Error):
+            core.conv3x3(d, d)
+
+
+def test_red_overlap(po):
+    w, h = 64, 48
+    base, frames = synth.webcam_stream(1, w, h, seed=12)
+    c, xs, df, _ = po.diff_pack(frames[0], base)
+    with CUDACore(w, h) as core:
+        d_img = to_dev(base)
+        core.red_overlap(d_img, to_dev(xs), None, c); core.synchronize()
+        assert np.array_equal(d_img.cpu().numpy(), po.red_overlap(base, xs))
+        d_img = to_dev(base)
+        d_cnt = torch.tensor([c], dtype=torch.int32, device=DEV)
+        core.red_overlap(d_img, to_dev(xs), d_cnt); core.synchronize()
+        assert np.array_equal(d_img.cpu().numpy(), po.red_overlap(base, xs))
+
+
+# ---- exec_core: the per-frame host path (kernels.cu:430-525) ---------------------------------------
+
+def oracle_exec(po, frame, state, vis, k, noise_filter, w, h):
+    """The reference's exec_core sequence on the CPU: [conv] -> [vis] -> diff -> [red]."""
+    cur = po.conv3x3(frame, w, h, k) if noise_filter else frame
+    show = None
+    if vis == lib.VIS_HEAT:
+        show = po.heat_map(cur, state)
+    elif vis == lib.VIS_GRAY:
+        show = po.gray_weighted(cur)
+    elif vis == lib.VIS_BINARIZE:
+        gw = po.gray_weighted(cur)
+        show = po.binarize(gw, po.two_max_threshold(po.histogram(gw)))
+    c, xs, df, new_state = po.diff_pack(cur, state)
+    if vis == lib.VIS_RED:
+        show = po.red_overlap(np.zeros_like(cur), xs)
+    elif vis == lib.VIS_RED_OVERLAP:
+        show = po.red_overlap(state, xs)
+    return c, xs, df, new_state, show
+
+
+@pytest.mark.parametrize("vis", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("noise_filter", [False, True])
+def test_exec_core_all_visualizers(po, vis, noise_filter):
+    w, h, T = 96, 54, 4
+    base, frames = synth.webcam_stream(T, w, h, seed=30 + vis)
+    k = po.gaussian_kernel(3, 1.5)
+    n = 3 * w * h
+    with CUDACore(w, h, k=k, sample_mat_data=base, visualizer=vis, noise_filter=noise_filter) as core:
+        h_frame, n_frame, o_frame, h_xs = CUDACore.alloc_arrays(h, w)
+        state = base
+        for t in range(T):
+            h_frame.array[:n] = frames[t]
+            pos = core.exec_core(h_frame.array, n_frame.array, "", h_xs.array)
+            c, xs, df, state, show = oracle_exec(po, frames[t], state, vis, k, noise_filter, w, h)
+            assert pos == c
+            assert np.array_equal(h_xs.array[:pos], xs)
+            assert np.array_equal(h_frame.array[:pos], df)
+            if show is not None:
+                assert np.array_equal(n_frame.array[:n], show)
+            assert np.array_equal(core.get_state(), state)
+        for a in (h_frame, n_frame, o_frame, h_xs):
+            a.free()
+
+
+def test_exec_core_text_overlay(po):
+    """kernel2_char (kernels.cu:351-375): glyph rows are blitted into the frame before the diff."""
+    w, h = 96, 54
+    gh, gw = 7, 5
+    charset = "0123456789BFPSWbkps :/"
+    rng = np.random.default_rng(1)
+    atlas = rng.integers(0, 256, (len(charset), gh, gw * 3), dtype=np.uint8)
+    base, frames = synth.webcam_stream(1, w, h, seed=40)
+    text = "FPS: 25"
+    exp = frames[0].reshape(h, w * 3).copy()
+    for j, ch in enumerate(text):
+        exp[:gh, j * gw * 3:(j + 1) * gw * 3] = atlas[charset.index(ch)]
+    exp = exp.reshape(-1)
+    with CUDACore(w, h, sample_mat_data=base, chars_px=atlas, chars_sz=(gh, gw), charset=charset) as core:
+        h_frame, n_frame, o_frame, h_xs = CUDACore.alloc_arrays(h, w)
+        h_frame.array[:3 * w * h] = frames[0]
+        pos = core.exec_core(h_frame.array, None, text, h_xs.array)
+        c, xs, df, st = po.diff_pack(exp, base)
+        assert pos == c and np.array_equal(h_xs.array[:pos], xs) and np.array_equal(h_frame.array[:pos], df)
+        assert np.array_equal(core.get_state(), st)
+
+
+def test_exec_core_1080p(po):
+    w, h = 1920, 1080
+    base, frames = synth.webcam_stream(2, w, h, device=DEV)
+    base, frames = base.cpu().numpy(), frames.cpu().numpy()
+    n = 3 * w * h
+    with CUDACore(w, h, sample_mat_data=base) as core:
+        h_frame, n_frame, o_frame, h_xs = CUDACore.alloc_arrays(h, w)
+        state = base
+        for t in range(2):
+            h_frame.array[:n] = frames[t]
+            pos = core.exec_core(h_frame.array, None, "", h_xs.array)
+            c, xs, df, state = po.diff_pack(frames[t], state)
+            assert pos == c and np.array_equal(h_xs.array[:pos], xs) and np.array_equal(h_frame.array[:pos], df)

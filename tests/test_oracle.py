@@ -1,0 +1,243 @@
+"""CPU tests of the oracle itself: pinned against the reference's own outputs and identities
+ and against the committed golden vectors."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from cudavideostream_amd import synth
+
+REF_PRESENT = os.path.exists("/root/reference/server/src/server.cpp")
+
+
+# ---- pinned by the reference itself -------------------------------------------------------------
+
+def test_cpu_branch_matches_reference_fixture(po):
+    """gray-avg -> histogram -> two-max -> binarize == the reference's server.cpp CPU branch
+    (outputs recorded from oracle/_ref/server_cpu, i.e. server/src/server.cpp:96-135 itself)."""
+    g = golden("ref_server_cpu_64x48.npz")
+    thrs = []
+    for t in range(g["frames"].shape[0]):
+        out, thr = po.server_cpu_branch(g["frames"][t])
+        thrs.append(thr)
+        assert np.array_equal(out, g["out"][t]), f"frame {t}"
+    assert 50 in thrs and 200 in thrs  # both clamps of server.cpp:122-127 are exercised
+
+
+@pytest.mark.skipif(not REF_PRESENT, reason="reference tree not present (GPU box)")
+def test_cpu_branch_matches_reference_live(po, tmp_path):
+    """Same check against a fresh run of the reference binary on new random frames."""
+    po.build()
+    rng = np.random.default_rng(7)
+    w, h = 40, 30
+    base = rng.integers(0, 256, 3 * w * h, dtype=np.uint8)
+    frames = rng.integers(0, 256, (8, 3 * w * h), dtype=np.uint8)
+    frames[3] //= 5
+    frames[5] = 255 - frames[5] // 7
+    out = po.run_ref_server_cpu(base, frames, w, h, str(tmp_path))
+    for t in range(8):
+        mine, _ = po.server_cpu_branch(frames[t])
+        assert np.array_equal(mine, out[t])
+
+
+def test_two_max_dead_branch(po):
+    """server.cpp:116 `else if` can never fire (sec_max == max after every record)."""
+    rng = np.random.default_rng(3)
+    for _ in range(2000):
+        hist = rng.integers(0, 50, 256).astype(np.int32)
+        idx, sec = -1, -1
+        mx = -1
+        for i in range(256):  # prefix-maximum records
+            if hist[i] >= mx:
+                sec, idx, mx = idx, i, hist[i]
+        thr = min(200, max(50, int((idx + sec) / 2)))
+        assert po.two_max_threshold(hist) == thr
+
+
+def test_integer_diff_identity(po):
+    """tests/algorithms_benchmarks.cu:12-22: frame1 - frame2 == diff (with its own index quirk)."""
+    L = po.lib()
+    h, w = 1920, 1080  # as called at algorithms_benchmarks.cu:106
+    n = h * w * 3
+    a = np.empty(n, np.int32); b = np.empty(n, np.int32); d = np.empty(n, np.int32)
+    L.ora_generate_image(a, h, w, 1)
+    L.ora_generate_image(b, h, w, 2)
+    assert a.min() >= 0 and a.max() <= 254       # rand() % 255
+    L.ora_int_diff(a, b, d, n)
+    assert L.ora_check_difference(a, b, d, h, w) == 0
+    d[5] += 1
+    assert L.ora_check_difference(a, b, d, h, w) == -1
+
+
+def test_count_identity(po):
+    """tests/test_cuda/pixel_diff.cu:47-59: #(cur != prev) == #(diff != 0) (threshold 0)."""
+    rng = np.random.default_rng(11)
+    cur = rng.integers(0, 4, 50000, dtype=np.uint8)
+    prev = rng.integers(0, 4, 50000, dtype=np.uint8)
+    c, xs, df, _ = po.diff_pack(cur, prev, thr=0)
+    assert c == int((cur != prev).sum()) == int((df != 0).sum())
+
+
+def test_client_reconstruction_identity(po):
+    """client/opencv.cpp:64-66: prev[xs] += diff rebuilds exactly the server's state."""
+    base, frames = synth.webcam_stream(4, 48, 32, seed=2)
+    client = base.copy()
+    state = base.copy()
+    for t in range(4):
+        c, xs, df, state = po.diff_pack(frames[t], state)
+        client = po.client_apply(client, xs, df)
+        assert np.array_equal(client, state)
+        # everything the client does not know is within the threshold of the true frame
+        assert np.abs(client.astype(int) - frames[t].astype(int)).max() <= 20
+
+
+def test_inplace_form_matches(po):
+    """test.cu:567 writes the diff bytes over the head of the frame buffer."""
+    rng = np.random.default_rng(5)
+    cur = rng.integers(0, 256, 9000, dtype=np.uint8)
+    prev = rng.integers(0, 256, 9000, dtype=np.uint8)
+    c, xs, df, st = po.diff_pack(cur, prev)
+    buf, st2 = cur.copy(), prev.copy()
+    xs2 = np.empty(9000, np.int32)
+    c2 = po.lib().ora_diff_pack_inplace(buf, st2, 9000, 20, xs2)
+    assert c2 == c and np.array_equal(xs2[:c], xs) and np.array_equal(buf[:c], df)
+    assert np.array_equal(st2, st)
+
+
+def test_mt_matches_single_thread(po):
+    rng = np.random.default_rng(6)
+    cur = rng.integers(0, 256, 100003, dtype=np.uint8)
+    prev = rng.integers(0, 256, 100003, dtype=np.uint8)
+    ref = po.diff_pack(cur, prev)
+    for nt in (1, 2, 7, 8, 64):
+        got = po.diff_pack_mt(cur, prev, nthreads=nt)
+        assert got[0] == ref[0]
+        for a, b in zip(got[1:], ref[1:]):
+            assert np.array_equal(a, b)
+
+
+# ---- semantics at the threshold -------------------------------------------------------------------
+
+def test_edge_strip_threshold_semantics(po):
+    cur, prev = synth.edge_strip()
+    c, xs, df, st = po.diff_pack(cur, prev)
+    d = cur.astype(int) - prev.astype(int)
+    flagged = np.abs(d) > 20  # strict >, kernels.cu:312
+    assert c == int(flagged.sum())
+    assert np.array_equal(xs, np.nonzero(flagged)[0].astype(np.int32))
+    assert np.array_equal(df, (d[flagged] & 0xFF).astype(np.uint8))
+    assert np.array_equal(st, np.where(flagged, cur, prev))
+    g = golden("oracle_diff_edge_strip.npz")
+    assert c == int(g["count"]) and np.array_equal(xs, g["xs"]) and np.array_equal(df, g["diff"])
+
+
+def test_static_flip_empty(po):
+    cur, prev = synth.static_pair(5000)
+    assert po.diff_pack(cur, prev)[0] == 0
+    cur, prev = synth.flip_pair(5000)
+    c, xs, _, st = po.diff_pack(cur, prev)
+    assert c == 5000 and np.array_equal(xs, np.arange(5000, dtype=np.int32)) and np.array_equal(st, cur)
+    c, xs, df, st = po.diff_pack(np.empty(0, np.uint8), np.empty(0, np.uint8))
+    assert c == 0 and xs.size == 0 and st.size == 0
+
+
+# ---- golden vectors ---------------------------------------------------------------------------------
+
+def test_golden_stream(po):
+    g = golden("oracle_diff_stream_64x48.npz")
+    offsets, xs, df, st = po.diff_stream(g["frames"], g["base"])
+    assert np.array_equal(offsets, g["offsets"]) and np.array_equal(xs, g["xs"])
+    assert np.array_equal(df, g["diff"]) and np.array_equal(st, g["state"])
+
+
+def test_golden_ragged(po):
+    g = golden("oracle_diff_ragged_37x11.npz")
+    c, xs, df, st = po.diff_pack(g["cur"], g["prev"])
+    assert c == int(g["count"]) and np.array_equal(xs, g["xs"]) and np.array_equal(df, g["diff"])
+    assert np.array_equal(st, g["state"])
+
+
+def test_golden_filters(po):
+    g = golden("oracle_filters_64x48.npz")
+    w, h, img, prv = int(g["width"]), int(g["height"]), g["img"], g["prev"]
+    assert np.array_equal(po.gray_avg(img), g["gray_avg"])
+    gw = po.gray_weighted(img)
+    assert np.array_equal(gw, g["gray_weighted"])
+    assert np.array_equal(po.histogram(gw), g["hist"])
+    assert po.two_max_threshold(g["hist"]) == int(g["thr"])
+    assert np.array_equal(po.binarize(gw, int(g["thr"])), g["binarized"])
+    assert np.array_equal(po.heat_map(img, prv), g["heat"])
+    assert np.array_equal(po.red_dense(img, prv), g["red"])
+    assert np.array_equal(po.conv3x3(img, w, h, g["k"]), g["conv"])
+
+
+def test_heat_lut_spot_values(po):
+    """SURVEY.md section 8a-7 spot values (normaliser 510: red falls off again above d=510)."""
+    lut = po.heat_lut()
+    assert np.array_equal(lut, golden("oracle_heat_lut.npz")["lut"])
+    bgr = {0: (255, 0, 0), 1: (254, 1, 0), 255: (0, 255, 0), 510: (0, 0, 255), 600: (0, 0, 216),
+           765: (0, 0, 0)}
+    for d, v in bgr.items():
+        assert tuple(lut[d]) == v
+
+
+def test_gaussian_kernel(po):
+    k = po.gaussian_kernel(3, 1.5)  # server.cpp:43 sigma = K*K/6.0
+    assert np.array_equal(k, golden("oracle_gaussian_k3.npz")["k"])
+    assert abs(float(k.sum()) - 1.0) < 1e-6 and k[4] == k.max()
+    assert k[0] == k[2] == k[6] == k[8] and k[1] == k[3] == k[5] == k[7]
+
+
+def test_gray_weighted_sample_and_numpy(po):
+    g = golden("oracle_gray_weighted_sample.npz")
+    bgr = g["bgr"]
+    got = po.gray_weighted(bgr.reshape(-1)).reshape(-1, 3)
+    assert np.array_equal(got[:, 0], g["gray"]) and np.array_equal(got[:, 1], got[:, 2])
+    # same expression in numpy float64, left to right (tests/grayscale-weighted/cpu.cu:40)
+    v = 0.114 * bgr[:, 0].astype(np.float64) + 0.587 * bgr[:, 1] + 0.299 * bgr[:, 2]
+    assert np.array_equal(v.astype(np.uint8), g["gray"])
+
+
+def test_conv_known_small_image(po):
+    """3x3x3 hand image of tests/noise_filter_benchmark/v1.cu:122 (expected values are not recorded
+    upstream): the float path must agree with exact rational arithmetic after truncation wherever the
+    exact value is not within 1e-4 of an integer; borders see the zero halo."""
+    img = np.array([1, 0, 120, 2, 0, 139, 3, 0, 90, 4, 0, 99, 5, 0, 126, 6, 0, 106, 7, 0, 46, 8, 0, 75,
+                    9, 0, 88], np.uint8)
+    k = po.gaussian_kernel(3, 1.5)
+    out = po.conv3x3(img, 3, 3, k).reshape(3, 3, 3)
+    src = img.reshape(3, 3, 3).astype(np.float64)
+    pad = np.zeros((5, 5, 3)); pad[1:4, 1:4] = src
+    k64 = k.astype(np.float64).reshape(3, 3)
+    for y in range(3):
+        for x in range(3):
+            for c in range(3):
+                exact = float((pad[y:y + 3, x:x + 3, c] * k64).sum())
+                if abs(exact - round(exact)) > 1e-4:
+                    assert out[y, x, c] == int(exact)
+    assert (out[:, :, 1] == 0).all()
+
+
+def test_red_overlap(po):
+    img = np.zeros(30, np.uint8)
+    out = po.red_overlap(img, np.array([0, 4, 8, 29], np.int32))
+    assert np.array_equal(np.nonzero(out)[0], [2, 5, 8, 29])
+
+
+# ---- synthetic inputs ---------------------------------------------------------------------------------
+
+def test_synth_properties(po):
+    a = synth.refrand_frame(200000, 1)
+    b = synth.refrand_frame(200000, 2)
+    assert a.max() <= 254 and 0.83 < po.diff_pack(a, b)[0] / a.size < 0.86
+    base, frames = synth.webcam_stream(3, 192, 108)
+    st = base
+    fr = []
+    for t in range(3):
+        c, _, _, st = po.diff_pack(frames[t], st)
+        fr.append(c / base.size)
+    assert 0.01 < fr[1] < 0.06 and 0.01 < fr[2] < 0.06  # webcam-like sparsity
+    torch = pytest.importorskip("torch")
+    tb, tf = synth.webcam_stream(2, 192, 108, device="cpu")
+    assert np.array_equal(tb.numpy(), base) and np.array_equal(tf.numpy(), frames[:2])
