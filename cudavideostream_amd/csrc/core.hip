@@ -135,7 +135,8 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     if (nframes < 0 || nframes > c->cfg.max_batch)
         return fail(MI355_ERR_INVALID, "nframes outside [0, max_batch]");
     if (!d_offsets) return fail(MI355_ERR_INVALID, "null d_offsets");
-    if (nframes > 0 && (!d_cur || (pair && !d_prev))) return fail(MI355_ERR_INVALID, "null frame pointer");
+    if (nframes > 0 && c->n > 0 && (!d_cur || (pair && !d_prev)))
+        return fail(MI355_ERR_INVALID, "null frame pointer");
     if (nframes > 0 && stride < c->n) return fail(MI355_ERR_INVALID, "stride_bytes < frame bytes");
     if (capacity > 0 && (!d_xs || !d_diff)) return fail(MI355_ERR_INVALID, "null output pointer");
     if (int rc = use_device(c)) return rc;

@@ -21,6 +21,12 @@
 
 namespace mi355 {
 
+// Ablation builds (tools/ablate.sh, never shipped): 1 = no log appends, 2 = also no cnt/logpos stores,
+// 3 = loads + state fold only (memory floor of the stream loop).  0 = the product.
+#ifndef MI355_ABLATE
+#define MI355_ABLATE 0
+#endif
+
 constexpr int kPrefetch = 4;  // frames in flight per wave (4 x 1 KiB; ~24 waves/CU -> ~96 KiB/CU)
 
 // ---- wave64 inclusive scan with DPP (row_shr within rows of 16, then row_bcast 15 / 31) ---------
@@ -88,6 +94,10 @@ __device__ __forceinline__ uint4 load16(const uint8_t *p, int valid) {
 __device__ __forceinline__ uint32_t pack_step(const uint4 c, uint4 &s, int thr, uint32_t thr2,
                                               uint32_t byte_off, int32_t *log_xs, uint8_t *log_diff,
                                               size_t log_base) {
+#if MI355_ABLATE == 3
+    s.x ^= c.x; s.y ^= c.y; s.z ^= c.z; s.w ^= c.w;
+    return 0;
+#endif
     const uint32_t f0 = dword_flags(c.x, s.x, thr, thr2);
     const uint32_t f1 = dword_flags(c.y, s.y, thr, thr2);
     const uint32_t f2 = dword_flags(c.z, s.z, thr, thr2);
@@ -102,7 +112,11 @@ __device__ __forceinline__ uint32_t pack_step(const uint4 c, uint4 &s, int thr, 
         const uint32_t d0 = bytes_sub(c.x, s.x), d1 = bytes_sub(c.y, s.y);
         const uint32_t d2 = bytes_sub(c.z, s.z), d3 = bytes_sub(c.w, s.w);
         size_t o = log_base + (uint32_t)(incl - cnt);
-        do {
+#if MI355_ABLATE >= 1
+        asm volatile("" ::"v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(o));
+        m = 0;
+#endif
+        while (m) {
             const int j = __builtin_ctz(m);
             m &= m - 1;
             const int k = j >> 2;
@@ -110,7 +124,7 @@ __device__ __forceinline__ uint32_t pack_step(const uint4 c, uint4 &s, int thr, 
             log_xs[o] = (int32_t)(byte_off + (uint32_t)j);          // kernels.cu:315
             log_diff[o] = (uint8_t)(dw >> (8 * (j & 3)));           // kernels.cu:314
             ++o;
-        } while (m);
+        }
         // negative feedback (kernels.cu:316-331): un-flagged bytes keep the previous value, flagged
         // bytes take the current one -> the state is the frame the client reconstructs.
         const uint32_t m0 = expand4(f0), m1 = expand4(f1), m2 = expand4(f2), m3 = expand4(f3);
@@ -154,7 +168,7 @@ __device__ __forceinline__ void pack_group(const PackArgs &a, const Group<PAIR, 
             if (PAIR) st = g.p[d];
             const uint32_t total =
                 pack_step(g.c[d], st, a.thr, thr2, byte_off, a.log_xs, a.log_diff, tile_log + run);
-            if (lane == 0) {
+            if (lane == 0 && MI355_ABLATE < 2) {
                 a.cnt[(size_t)t * a.ntiles + tile] = total;
                 a.logpos[(size_t)t * a.ntiles + tile] = run;
             }

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Profiles bench.py's hot path on the GPU box (run through gpurun from the repo root):
+#   1. rocprofv3 --kernel-trace --stats      -> per-kernel durations
+#   2. rocprofv3 --pmc FETCH_SIZE            -> HBM read bytes   (separate pass, see MI355X_MICROARCH.md)
+#   3. rocprofv3 --pmc WRITE_SIZE            -> HBM write bytes  (separate pass)
+# Raw output goes to gpurun_out/prof_<tag>/ (scratch); profiles/summarize.py condenses it into the
+# committed profiles/<tag>_*.{csv,json}.
+set -u
+TAG=${1:-r01}
+STEPS=${2:-5}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ARGS="bench.py --steps $STEPS --warmup 2 --no-cpu --no-pair"
+cd $ROOT
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || echo "trace failed"
+# counter passes run the C++ harness (same workload, same library): rocprofv3's counter collection
+# crashes inside PyTorch's own elementwise kernels on this image
+DB="tools/diffbench --steps $STEPS --warmup 2"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $DB > $OUT/fetch.log 2>&1 || echo "fetch failed"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $DB > $OUT/write.log 2>&1 || echo "write failed"
+find $OUT -name "*.csv" | head -20
+python3 profiles/summarize.py $OUT $TAG || true

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 CSV output (gpurun_out/prof_<tag>/) into small committed summaries:
+  profiles/<tag>_kernel_stats.csv : per-kernel calls / total / average duration (kernel-trace --stats)
+  profiles/<tag>_pmc.json         : FETCH_SIZE / WRITE_SIZE per launch of the pack kernel, raw and with
+                                    the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE reports 1/2
+                                    of a wide coalesced read stream; both counters are in KiB)
+  profiles/pmc_summary.json       : what bench.py reports as roofline.traffic
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+src, tag = sys.argv[1], sys.argv[2]
+here = os.path.dirname(os.path.abspath(__file__))
+
+
+def find(sub, pat):
+    r = glob.glob(os.path.join(src, sub, "**", pat), recursive=True)
+    return r[0] if r else None
+
+
+def kernel_rows(path):
+    with open(path) as f:
+        return list(csv.DictReader(f))
+
+
+stats = find("trace", "*kernel_stats.csv")
+if stats:
+    rows = kernel_rows(stats)
+    keep = [r for r in rows if "mi355" in r.get("Name", "")]
+    with open(os.path.join(here, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        for r in keep:
+            w.writerow(r)
+    for r in keep:
+        print(r["Name"][:60], r.get("Calls"), r.get("AverageNs"), r.get("Percentage"))
+
+trace = find("trace", "*kernel_trace.csv")
+if trace:
+    per = defaultdict(list)
+    for r in kernel_rows(trace):
+        per[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for k, v in per.items():
+        if "mi355" in k:
+            v2 = sorted(v)
+            print(f"trace {k[:50]}: n={len(v)} avg={sum(v)/len(v)/1e3:.1f}us med={v2[len(v2)//2]/1e3:.1f}us")
+
+pmc = {}
+for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    p = find(sub, "*counter_collection.csv")
+    if not p:
+        continue
+    vals = defaultdict(list)
+    for r in kernel_rows(p):
+        if r.get("Counter_Name") == ctr:
+            vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for k, v in vals.items():
+        if "k_diff_pack" in k:
+            big = [x for x in v if x > 0.5 * max(v)]  # the 256-frame launches, not the tiny checker ones
+            pmc[ctr] = {"kernel": k, "launches": len(big), "avg_raw_KiB": sum(big) / len(big)}
+if pmc:
+    f_raw = pmc.get("FETCH_SIZE", {}).get("avg_raw_KiB")
+    w_raw = pmc.get("WRITE_SIZE", {}).get("avg_raw_KiB")
+    out = {"tag": tag, "counters": pmc,
+           "note": "rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts 64 B per "
+                   "128-B request of a wide coalesced read stream, so read bytes = 2 x FETCH_SIZE "
+                   "(MI355X_MICROARCH.md, HBM); WRITE_SIZE is exact for 16-B-per-lane stores and "
+                   "uncalibrated for the narrow log stores of this kernel"}
+    if f_raw is not None:
+        out["read_bytes_per_launch"] = 2 * f_raw * 1024
+    if w_raw is not None:
+        out["write_bytes_per_launch"] = w_raw * 1024
+    json.dump(out, open(os.path.join(here, f"{tag}_pmc.json"), "w"), indent=1)
+    if f_raw is not None and w_raw is not None:
+        json.dump({"tag": tag, "batch": 256, "width": 1920, "height": 1080,
+                   "hbm_bytes_per_launch": int(2 * f_raw * 1024 + w_raw * 1024),
+                   "source": f"profiles/{tag}_pmc.json"},
+                  open(os.path.join(here, "pmc_summary.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))

@@ -1,0 +1,129 @@
+// tools/diffbench.hip -- C++ harness over the C-ABI (include/mi355diff.h): the same workload as
+// bench.py (S1 `webcam` stream, B frames resident in HBM, stateful diff+threshold+pack) without
+// Python/PyTorch in the process.  Used for the rocprofv3 --pmc passes (the counter-collection
+// interposer crashes under PyTorch's own kernels on this image) and as a plain C++ example of the
+// boundary.  The synthetic generator is a device-side restatement of cudavideostream_amd/synth.py
+// (tests/test_tools_gpu.py checks the two produce identical bytes).
+//
+//   diffbench [--width W] [--height H] [--batch B] [--steps K] [--warmup W] [--seed S]
+//             [--pairs] [--checksum T]
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../include/mi355diff.h"
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(3); } } while (0)
+#define MI_OK(x) do { int r_ = (x); if (r_ != 0) { fprintf(stderr, "%s: %s\n", #x, mi355_last_error()); exit(4); } } while (0)
+
+__host__ __device__ inline uint32_t hash32(uint32_t x) {  // lowbias32, synth.py hash32
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
+// synth.py webcam_frame(t, width, height, seed): t = -1 is the base frame.
+__global__ void k_webcam_frame(uint8_t *out, int t, int width, int height, uint32_t seed) {
+    const uint32_t n = 3u * width * height;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const uint32_t tt = (uint32_t)(t + 1) & 0xFFFFu;
+    const uint32_t key = hash32(hash32(idx) + tt * 0x9E3779B9u + seed * 0x85EBCA6Bu);
+    const int nz = (int)((key & 0xFFFFu) % 17u) - 8;
+    const uint32_t pix = idx / 3u;
+    const int c = (int)(idx - pix * 3u);
+    const int y = (int)(pix / (uint32_t)width), x = (int)(pix % (uint32_t)width);
+    const int tex = (int)((hash32(idx + 0x5BD1E995u) >> 8) % 7u);
+    int val = 40 + (x * 150) / width + (y * 40) / height + 5 * c + tex;
+    if (t >= 0) {
+        const int rw = width / 4, rh = height / 4;
+        const int speed = width / 240 > 1 ? width / 240 : 1;
+        const int x0 = (t * speed) % (width - rw), y0 = height / 3;
+        if (x >= x0 && x < x0 + rw && y >= y0 && y < y0 + rh) val = 120 + 10 * c + (x - x0) / 16;
+    }
+    val += nz;
+    if (t >= 0 && ((key >> 16) & 0xFFFFu) < 786u) val = (int)(hash32(key ^ 0xABCDEFu) & 0xFFu);
+    out[idx] = (uint8_t)(val < 0 ? 0 : val > 255 ? 255 : val);
+}
+
+int main(int argc, char **argv) {
+    int W = 1920, H = 1080, B = 256, K = 20, WU = 3, checksum_t = -2;
+    uint32_t seed = 21;
+    bool pairs = false;
+    for (int i = 1; i < argc; i++) {
+        auto next = [&](int &v) { if (i + 1 < argc) v = atoi(argv[++i]); };
+        if (!strcmp(argv[i], "--width")) next(W);
+        else if (!strcmp(argv[i], "--height")) next(H);
+        else if (!strcmp(argv[i], "--batch")) next(B);
+        else if (!strcmp(argv[i], "--steps")) next(K);
+        else if (!strcmp(argv[i], "--warmup")) next(WU);
+        else if (!strcmp(argv[i], "--seed")) { int s = 21; next(s); seed = (uint32_t)s; }
+        else if (!strcmp(argv[i], "--checksum")) next(checksum_t);
+        else if (!strcmp(argv[i], "--pairs")) pairs = true;
+    }
+    const size_t n = (size_t)3 * W * H;
+    if (checksum_t >= -1) {  // print a checksum of one generated frame (generator cross-check)
+        uint8_t *d; HIP_OK(hipMalloc((void **)&d, n));
+        hipLaunchKernelGGL(k_webcam_frame, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d, checksum_t, W, H, seed);
+        std::vector<uint8_t> h(n);
+        HIP_OK(hipMemcpy(h.data(), d, n, hipMemcpyDeviceToHost));
+        uint64_t s1 = 0, s2 = 0;
+        for (size_t i = 0; i < n; i++) { s1 += h[i]; s2 += (uint64_t)h[i] * (uint64_t)(i % 65521 + 1); }
+        printf("{\"frame\": %d, \"sum\": %llu, \"wsum\": %llu}\n", checksum_t, (unsigned long long)s1, (unsigned long long)s2);
+        return 0;
+    }
+
+    mi355_config cfg{};
+    cfg.width = W; cfg.height = H; cfg.threshold = 20; cfg.max_batch = B; cfg.device = -1;
+    mi355_core *core = nullptr;
+    MI_OK(mi355_create(&cfg, &core));
+
+    uint8_t *d_frames = nullptr, *d_base = nullptr;
+    HIP_OK(hipMalloc((void **)&d_frames, n * (size_t)(B + 1)));
+    HIP_OK(hipMalloc((void **)&d_base, n));
+    const dim3 g((unsigned)((n + 255) / 256)), b(256);
+    hipLaunchKernelGGL(k_webcam_frame, g, b, 0, 0, d_base, -1, W, H, seed);
+    for (int t = 0; t <= B; t++)
+        hipLaunchKernelGGL(k_webcam_frame, g, b, 0, 0, d_frames + (size_t)t * n, t, W, H, seed);
+    HIP_OK(hipDeviceSynchronize());
+    std::vector<uint8_t> h_base(n);
+    HIP_OK(hipMemcpy(h_base.data(), d_base, n, hipMemcpyDeviceToHost));
+    MI_OK(mi355_set_state(core, h_base.data()));
+
+    const size_t cap = (size_t)B * n / 8 > (1u << 20) ? (size_t)B * n / 8 : (1u << 20);
+    uint32_t *d_off; int32_t *d_xs; uint8_t *d_df;
+    HIP_OK(hipMalloc((void **)&d_off, sizeof(uint32_t) * (B + 1)));
+    HIP_OK(hipMalloc((void **)&d_xs, sizeof(int32_t) * cap));
+    HIP_OK(hipMalloc((void **)&d_df, cap));
+
+    auto step = [&]() {
+        if (pairs) MI_OK(mi355_diff_pairs_batch(core, d_frames + n, d_frames, n, B, d_off, d_xs, d_df, cap));
+        else MI_OK(mi355_diff_stream_batch(core, d_frames, n, B, d_off, d_xs, d_df, cap));
+    };
+    for (int i = 0; i < WU; i++) step();
+    MI_OK(mi355_synchronize(core));
+    MI_OK(mi355_set_timing(core, 1));
+    MI_OK(mi355_reset_timing(core));
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    for (int i = 0; i < K; i++) step();
+    MI_OK(mi355_synchronize(core));
+    const double sec = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    double ms_pack = 0, ms_total = 0; int launches = 0;
+    MI_OK(mi355_get_timing(core, &ms_pack, &ms_total, &launches));
+    std::vector<uint32_t> off(B + 1);
+    HIP_OK(hipMemcpy(off.data(), d_off, sizeof(uint32_t) * (B + 1), hipMemcpyDeviceToHost));
+    const double p = off[B];
+    const double pack_ms = ms_pack / (launches ? launches : 1);
+    const double alg = 2.0 * n * B + 5.0 * p;
+    printf("{\"harness\": \"diffbench\", \"mode\": \"%s\", \"width\": %d, \"height\": %d, \"batch\": %d, \"steps\": %d, "
+           "\"frames_per_s\": %.1f, \"kernel_ms\": %.4f, \"all_kernels_ms\": %.4f, \"changed_bytes_per_frame\": %.1f, "
+           "\"achieved_gbps\": %.1f, \"workspace_bytes\": %zu}\n",
+           pairs ? "pairs" : "stream", W, H, B, K, (double)B * K / sec, pack_ms, ms_total / (launches ? launches : 1),
+           p / B, alg / (pack_ms * 1e-3) / 1e9, mi355_workspace_bytes(core));
+    mi355_destroy(core);
+    return 0;
+}
