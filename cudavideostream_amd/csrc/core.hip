@@ -5,9 +5,10 @@
 //   state     N            the client's reconstructed frame (d_current/d_previous pair of the
 //                          reference collapsed into one persistent buffer)
 //   in, aux, vis  N each   exec(): uploaded frame, filter scratch, visualisation frame
-//   log_xs    W*1024*T*4   per-tile append logs written by k_diff_pack (worst case: every byte of
-//   log_diff  W*1024*T     every frame flagged)
-//   cnt, logpos, segoff  T*W*4 each;  totals T*4;  offsets (T+1)*4
+//   rec       T*W*64*16    record log written by k_diff_pack: 16 masked diff bytes per candidate lane
+//                          (worst case: every lane of every frame), chunk-interleaved over tiles
+//   meta      T*W*16       per (frame, tile): candidate ballot, flagged-byte count, log position
+//   segoff    T*W*4;  totals T*4;  offsets (T+1)*4
 //   one_xs N*4, one_diff N exec(): packed output of a single frame before the D2H copies
 //   hist 256*4, thr 4, k9 9*4, heat LUT 766*3, glyph atlas
 #include <cmath>
@@ -49,14 +50,12 @@ struct mi355_core {
     int device = 0;
     uint32_t n = 0;        // bytes per frame
     uint32_t ntiles = 0;
-    uint32_t log_cap = 0;  // entries per tile log
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
 
     uint8_t *state = nullptr, *in = nullptr, *aux = nullptr, *vis = nullptr;
-    int32_t *log_xs = nullptr;
-    uint8_t *log_diff = nullptr;
-    uint32_t *cnt = nullptr, *logpos = nullptr, *segoff = nullptr, *totals = nullptr;
+    uint4 *rec = nullptr, *meta = nullptr;
+    uint32_t *segoff = nullptr, *totals = nullptr;
     uint32_t *offsets = nullptr;  // T+1, used by exec()
     int32_t *one_xs = nullptr;
     uint8_t *one_diff = nullptr;
@@ -159,29 +158,23 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     a.nframes = nframes;
     a.thr = c->cfg.threshold;
     a.ntiles = c->ntiles;
-    a.log_cap = c->log_cap;
-    a.log_xs = c->log_xs;
-    a.log_diff = c->log_diff;
-    a.cnt = c->cnt;
-    a.logpos = c->logpos;
+    a.rec = c->rec;
+    a.meta = c->meta;
     const bool aligned = (((uintptr_t)d_cur | (uintptr_t)d_prev | stride) & 15u) == 0;
     HIP_TRY(launch_diff_pack(a, pair, aligned, c->stream));
     if (tev) HIP_TRY(hipEventRecord(tev[1], c->stream));
-    HIP_TRY(launch_scan(c->cnt, c->segoff, c->totals, c->ntiles, nframes, (uint32_t *)d_offsets,
+    HIP_TRY(launch_scan(c->meta, c->segoff, c->totals, c->ntiles, nframes, (uint32_t *)d_offsets,
                         c->stream));
-    GatherArgs g{};
-    g.log_xs = c->log_xs;
-    g.log_diff = c->log_diff;
-    g.cnt = c->cnt;
-    g.logpos = c->logpos;
+    ExpandArgs g{};
+    g.rec = c->rec;
+    g.meta = c->meta;
     g.segoff = c->segoff;
     g.offsets = (const uint32_t *)d_offsets;
     g.ntiles = c->ntiles;
-    g.log_cap = c->log_cap;
     g.out_xs = (int32_t *)d_xs;
     g.out_diff = (uint8_t *)d_diff;
     g.capacity = capacity;
-    HIP_TRY(launch_gather(g, nframes, c->stream));
+    HIP_TRY(launch_expand(g, nframes, c->stream));
     if (tev) {
         HIP_TRY(hipEventRecord(tev[2], c->stream));
         c->ev_count += 1;
@@ -221,7 +214,6 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
 
     c->n = (uint32_t)n64;
     c->ntiles = (c->n + kTileBytes - 1) / kTileBytes;
-    c->log_cap = kTileBytes * (uint32_t)cfg->max_batch;
     const size_t T = (size_t)cfg->max_batch, W = c->ntiles, N = c->n;
 
     int rc = use_device(c);
@@ -232,10 +224,8 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (!rc) rc = dev_alloc(c, &c->in, N + 16);
     if (!rc) rc = dev_alloc(c, &c->aux, N + 16);
     if (!rc) rc = dev_alloc(c, &c->vis, N + 16);
-    if (!rc) rc = dev_alloc(c, &c->log_xs, W * c->log_cap);
-    if (!rc) rc = dev_alloc(c, &c->log_diff, W * c->log_cap);
-    if (!rc) rc = dev_alloc(c, &c->cnt, T * W);
-    if (!rc) rc = dev_alloc(c, &c->logpos, T * W);
+    if (!rc) rc = dev_alloc(c, &c->rec, T * W * 64);
+    if (!rc) rc = dev_alloc(c, &c->meta, T * W);
     if (!rc) rc = dev_alloc(c, &c->segoff, T * W);
     if (!rc) rc = dev_alloc(c, &c->totals, T);
     if (!rc) rc = dev_alloc(c, &c->offsets, T + 1);
@@ -262,8 +252,7 @@ void mi355_destroy(mi355_core *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->log_xs, c->log_diff, c->cnt, c->logpos,
-                    c->segoff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
+    void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->meta, c->segoff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
                     c->lut, c->glyphs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_count) (void)hipHostFree(c->h_count);

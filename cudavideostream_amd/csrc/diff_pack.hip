@@ -4,30 +4,44 @@
 // reproduces the CPU statement of the same step (tests/cuda_streaming/test.cu:560-576): ascending
 // byte order, bounded, no atomics.
 //
-// Structure (HBM-bound byte streaming; no MFMA):
+// The path is byte streaming, but on gfx950 an integer VALU instruction occupies a SIMD for 4 cycles
+// per wave64, so at the HBM rate a wave has only ~100 VALU instructions per KiB: the kernel is built
+// around *bytes per instruction*, not around the memory system alone.
+//
 //   k_diff_pack : one wave64 owns one 1 KiB tile of the frame (lane l = bytes 16l..16l+15, one
 //                 global_load_dwordx4 per lane per frame) for ALL frames of the batch.  In stream mode
 //                 the tile's state lives in 4 VGPRs per lane across the batch, so a frame costs N
-//                 bytes of HBM reads instead of 2N; frames are prefetched kPrefetch deep in a
-//                 register ring.  Per frame the wave compares 16 bytes per lane, scans the per-lane
-//                 counts with DPP, and appends its (index, diff) entries to the tile's private log
-//                 (sequential appends: consecutive frames share cache lines, so the sparse output
-//                 leaves L2 as full lines).  It also records cnt[t][tile] and logpos[t][tile].
-//   k_scan_*    : per frame exclusive scan of cnt over tiles, then scan of the frame totals.
-//   k_gather    : copies the log segments into the caller's packed, frame-major, ascending arrays.
+//                 bytes of HBM reads instead of 2N; frames are double buffered in two register groups.
+//                 Per frame and dword, 4 bytes at a time (SWAR + v_bitop3 + v_perm):
+//                   flags   9 ops  exact 9-bit compare of 4 bytes (dword_flags)
+//                   select  2 ops  v_perm selector from the flags
+//                   state   1 op   v_perm(cur, state)          negative feedback
+//                   diff    3 ops  per-byte (cur - state), zeroed where un-flagged
+//                   count   3 ops per 16 bytes (sum of the four selectors, v_sad_u8)
+//                 A lane with at least one flagged byte is a *candidate*; candidates are ranked with
+//                 one ballot + mbcnt and each stores its 16 masked diff bytes as ONE 16-byte record
+//                 (un-flagged bytes are 0; a flagged byte is never 0 because |df| > T >= 0).  Records
+//                 of a tile are appended to a chunk-interleaved log (consecutive frames fill whole
+//                 cache lines; all tiles' current chunks are neighbours in memory).  Per (frame, tile)
+//                 one 16-byte meta word keeps {candidate ballot, flagged-byte count, log position}.
+//   k_scan_*    : per frame exclusive scan of the byte counts over tiles, then scan of the frame totals.
+//   k_expand    : one wave per tile again, streaming the tile's log: turns records into the caller's
+//                 packed, frame-major, ascending (xs, diff) arrays.
 // No inter-workgroup communication inside a launch, no spin waits, results independent of dispatch
 // order.
 #include "internal.h"
 
 namespace mi355 {
 
-// Ablation builds (tools/ablate.sh, never shipped): 1 = no log appends, 2 = also no cnt/logpos stores,
-// 3 = loads + state fold only (memory floor of the stream loop).  0 = the product.
+// Ablation builds (tools/ablate.sh, never shipped): 1 = no record stores, 2 = also no meta stores,
+// 3 = loads + state fold only (memory floor of the stream loop), 4 / 5 = record store of one lane /
+// of all 64 lanes (bytes vs instruction cost).  0 = the product.
 #ifndef MI355_ABLATE
 #define MI355_ABLATE 0
 #endif
 
-constexpr int kPrefetch = 4;  // frames in flight per wave (4 x 1 KiB; ~24 waves/CU -> ~96 KiB/CU)
+constexpr int kPrefetch = 4;  // frames per register group (two groups: 8 x 1 KiB in flight per wave)
+static_assert(kPrefetch % 2 == 0, "frames are processed in pairs");
 
 // ---- wave64 inclusive scan with DPP (row_shr within rows of 16, then row_bcast 15 / 31) ---------
 template <int CTRL, int ROW_MASK>
@@ -45,29 +59,49 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
     return v;
 }
 
-// ---- per-dword byte arithmetic ----------------------------------------------------------------------
-// 4-bit mask: bit j set iff |a.byte[j] - s.byte[j]| > thr     (kernels.cu:311-312)
-__device__ __forceinline__ uint32_t dword_flags(uint32_t a, uint32_t s, int thr, uint32_t thr2) {
-    uint32_t f = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int d = (int)((a >> (8 * j)) & 0xffu) - (int)((s >> (8 * j)) & 0xffu);
-        f |= ((uint32_t)(d + thr) > thr2) ? (1u << j) : 0u;
-    }
-    return f;
+// ---- per-dword byte arithmetic (4 bytes per instruction) --------------------------------------------
+constexpr uint32_t kH = 0x80808080u, kL = 0x7f7f7f7fu;
+
+struct ThrConst {   // per-byte replicated constants of the threshold T (0..127)
+    uint32_t ca;    // 127 - T : (x_l + ca) carries into bit 7  <=>  x_l >= T + 1
+    uint32_t cb;    // T       : (x_l + cb) carries into bit 7  <=>  x_l >= 128 - T
+};
+
+// v_bitop3_b32: arbitrary 3-input boolean function; the truth table is written as an expression over
+// the three operand patterns TA, TB, TC (same convention as the instruction's immediate).
+constexpr uint32_t TA = 0xF0, TB = 0xCC, TC = 0xAA;
+template <uint32_t TT>
+__device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT & 0xFFu);
 }
 
-// per-byte (a - s) mod 256                                     (kernels.cu:314 `diff[npos] = df`)
-__device__ __forceinline__ uint32_t bytes_sub(uint32_t a, uint32_t s) {
-    const uint32_t H = 0x80808080u;
-    return ((a | H) - (s & ~H)) ^ ((a ^ ~s) & H);
+// Exact |a.byte - s.byte| > T for the 4 bytes of a dword (kernels.cu:311-312): returns 0x80 in every
+// flagged byte, 0 elsewhere; x = (a | H) - (s & L) is handed back for the diff.  10 instructions.
+//   x = 128 + a_l - s_l per byte (never borrows across bytes); x7 = [a_l >= s_l], x_l = (a_l - s_l) mod 128.
+//   The true difference d = 128 (a7 - s7) + x - 128 is classified by its sign and by |d| >= 128:
+//     sure = (a7 ^ s7) & ~(a7 ^ x7)          |d| >= 128
+//     pos  = (a7 & ~s7) | (~(a7 ^ s7) & x7)  d >= 0 (else d < 0), |d| < 128, |d| mod 128 in x_l
+//     flagged = sure | (pos ? x_l >= T + 1 : x_l < 128 - T)
+__device__ __forceinline__ uint32_t dword_flags(uint32_t a, uint32_t s, ThrConst tc, uint32_t &x) {
+    x = (a | kH) - (s & kL);
+    const uint32_t xl = x & kL;
+    const uint32_t A = xl + tc.ca;                               // bit 7: x_l >= T + 1
+    const uint32_t nB = xl + tc.cb;                              // bit 7: x_l >= 128 - T
+    const uint32_t sure = bitop3<(TA ^ TB) & ~(TA ^ TC)>(a, s, x);
+    const uint32_t pos = bitop3<(TA & ~TB) | (~(TA ^ TB) & TC)>(a, s, x);
+    const uint32_t mag = bitop3<(TA & TB) | (~TA & ~TC)>(pos, A, nB);
+    return bitop3<(TA | TB) & TC>(sure, mag, kH);
 }
 
-// 4-bit mask -> 0xFF per selected byte
-__device__ __forceinline__ uint32_t expand4(uint32_t f) {
-    uint32_t x = (f * 0x00204081u) & 0x01010101u;
-    return (x << 8) - x;
+// per-byte (a - s) mod 256 from x: low 7 bits are x's, bit 7 is a7 ^ s7 ^ ~x7
+//                                                               (kernels.cu:314 `diff[npos] = df`)
+__device__ __forceinline__ uint32_t bytes_sub_from_x(uint32_t a, uint32_t s, uint32_t x) {
+    const uint32_t y = bitop3<(TA ^ TB ^ ~TC)>(a, s, x);
+    return bitop3<(TA & TB) | (~TA & TC)>(kH, y, x);
 }
+
+// v_perm selector: byte j picks byte j of the first operand where flagged, of the second otherwise
+__device__ __forceinline__ uint32_t perm_select(uint32_t fh) { return (fh >> 5) | 0x03020100u; }
 
 __device__ __forceinline__ uint4 load16_bytes(const uint8_t *p, int valid) {
     uint32_t w[4] = {0, 0, 0, 0};
@@ -84,56 +118,80 @@ __device__ __forceinline__ void store16_bytes(uint8_t *p, uint4 v, int valid) {
         if (i < valid) p[i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
 }
 
-template <bool FAST>
+// A stream's frames are read exactly once: non-temporal loads keep them from displacing the record
+// log and the meta words (written here, read back by k_expand) from the caches.  (Pair mode keeps
+// plain loads: callers often hand in overlapping cur/prev sequences that do hit.)
+#ifndef MI355_NT_LOADS
+#define MI355_NT_LOADS 1
+#endif
+template <bool FAST, bool NT = false>
 __device__ __forceinline__ uint4 load16(const uint8_t *p, int valid) {
+    if (FAST && NT) {
+#if MI355_NT_LOADS
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+#else
+        return *reinterpret_cast<const uint4 *>(p);
+#endif
+    }
     if (FAST) return *reinterpret_cast<const uint4 *>(p);
     return load16_bytes(p, valid);
 }
 
-// One frame of one tile: compare, update the state, append to the log.  Returns the wave's count.
-__device__ __forceinline__ uint32_t pack_step(const uint4 c, uint4 &s, int thr, uint32_t thr2,
-                                              uint32_t byte_off, int32_t *log_xs, uint8_t *log_diff,
-                                              size_t log_base) {
+// Record log: position `pos` of tile `tile` lives at record index
+//   ((pos / 64) * ntiles + tile) * 64 + pos % 64
+// (fits 32 bits: T * W * 64 = max_batch * N / 16 < 2^28; chunk and W are below 2^24)
+__device__ __forceinline__ uint32_t rec_index(uint32_t pos, uint32_t tile, uint32_t ntiles) {
+    return (__umul24(pos >> 6, ntiles) + tile) * 64u + (pos & 63u);
+}
+
+// One frame of one tile: compare, update the state, append the candidate records at log position
+// `run`.  Returns the candidate ballot; cnt4 receives 4 * (this lane's flagged bytes) + 24.
+__device__ __forceinline__ uint64_t pack_step(const uint4 c, uint4 &s, ThrConst tc, uint4 *rec_log,
+                                              uint32_t run, uint32_t tile, uint32_t ntiles,
+                                              uint32_t &cnt4) {
 #if MI355_ABLATE == 3
     s.x ^= c.x; s.y ^= c.y; s.z ^= c.z; s.w ^= c.w;
+    cnt4 = 24;
     return 0;
 #endif
-    const uint32_t f0 = dword_flags(c.x, s.x, thr, thr2);
-    const uint32_t f1 = dword_flags(c.y, s.y, thr, thr2);
-    const uint32_t f2 = dword_flags(c.z, s.z, thr, thr2);
-    const uint32_t f3 = dword_flags(c.w, s.w, thr, thr2);
-    uint32_t m = f0 | (f1 << 4) | (f2 << 8) | (f3 << 12);
-
-    const int cnt = __builtin_popcount(m);
-    const int incl = wave_inclusive_scan(cnt);
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
-
-    if (m) {
-        const uint32_t d0 = bytes_sub(c.x, s.x), d1 = bytes_sub(c.y, s.y);
-        const uint32_t d2 = bytes_sub(c.z, s.z), d3 = bytes_sub(c.w, s.w);
-        size_t o = log_base + (uint32_t)(incl - cnt);
-#if MI355_ABLATE >= 1
-        asm volatile("" ::"v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(o));
-        m = 0;
-#endif
-        while (m) {
-            const int j = __builtin_ctz(m);
-            m &= m - 1;
-            const int k = j >> 2;
-            const uint32_t dw = k == 0 ? d0 : k == 1 ? d1 : k == 2 ? d2 : d3;
-            log_xs[o] = (int32_t)(byte_off + (uint32_t)j);          // kernels.cu:315
-            log_diff[o] = (uint8_t)(dw >> (8 * (j & 3)));           // kernels.cu:314
-            ++o;
-        }
-        // negative feedback (kernels.cu:316-331): un-flagged bytes keep the previous value, flagged
-        // bytes take the current one -> the state is the frame the client reconstructs.
-        const uint32_t m0 = expand4(f0), m1 = expand4(f1), m2 = expand4(f2), m3 = expand4(f3);
-        s.x = (c.x & m0) | (s.x & ~m0);
-        s.y = (c.y & m1) | (s.y & ~m1);
-        s.z = (c.z & m2) | (s.z & ~m2);
-        s.w = (c.w & m3) | (s.w & ~m3);
+    const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+    uint32_t sw[4] = {s.x, s.y, s.z, s.w};
+    uint32_t dm[4], sel[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t x;
+        const uint32_t fh = dword_flags(cw[k], sw[k], tc, x);
+        sel[k] = perm_select(fh);
+        const uint32_t d = bytes_sub_from_x(cw[k], sw[k], x);
+        dm[k] = __builtin_amdgcn_perm(d, 0u, sel[k]);            // diff where flagged, 0 elsewhere
+        // negative feedback (kernels.cu:316-331): flagged bytes take the current value, the others
+        // keep the previous one -> the state is the frame the client reconstructs
+        sw[k] = __builtin_amdgcn_perm(cw[k], sw[k], sel[k]);
     }
-    return total;
+    s = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+    // every selector byte is j + 4*flag: the byte sum of the four selectors is 4*flags + 4*(0+1+2+3)
+    cnt4 = __builtin_amdgcn_sad_u8(sel[0] + sel[1] + sel[2] + sel[3], 0u, 0u);
+
+    const bool cand = ((dm[0] | dm[1]) | (dm[2] | dm[3])) != 0u;
+    const uint64_t mask = __ballot(cand);
+#if MI355_ABLATE >= 1 && MI355_ABLATE < 4
+    asm volatile("" ::"v"(dm[0]), "v"(dm[1]), "v"(dm[2]), "v"(dm[3]));
+#else
+#if MI355_ABLATE == 4   // same instruction stream, 1/19 of the bytes: only the first candidate stores
+    if (cand && __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)) == 0) {
+#elif MI355_ABLATE == 5 // every lane stores (1 KiB per step)
+    if (true) {
+#else
+    if (cand) {
+#endif
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        rec_log[rec_index(run + rank, tile, ntiles)] = make_uint4(dm[0], dm[1], dm[2], dm[3]);
+    }
+#endif
+    return mask;
 }
 
 // A group = kPrefetch consecutive frames of one tile held in registers.  Loads are always issued
@@ -151,7 +209,7 @@ struct Group {
 #pragma unroll
         for (int d = 0; d < kPrefetch; d++) {
             const int t = min(t0 + d, last);
-            c[d] = load16<FAST>(cp + (size_t)t * a.stride, valid);
+            c[d] = load16<FAST, !PAIR>(cp + (size_t)t * a.stride, valid);   // stream frames: read once
             if (PAIR) p[d] = load16<FAST>(pp + (size_t)t * a.stride, valid);
         }
     }
@@ -159,22 +217,37 @@ struct Group {
 
 template <bool PAIR, bool FAST>
 __device__ __forceinline__ void pack_group(const PackArgs &a, const Group<PAIR, FAST> &g, int t0,
-                                           uint4 &st, uint32_t &run, uint32_t tile, uint32_t byte_off,
-                                           size_t tile_log, uint32_t thr2, int lane) {
+                                           uint4 &st, uint32_t &run, uint32_t tile, ThrConst tc,
+                                           int lane) {
+    // The group's kPrefetch meta words are assembled in lanes 0..kPrefetch-1 and leave with ONE store.
+    uint4 meta = make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int d = 0; d < kPrefetch; d++) {
+    for (int d = 0; d < kPrefetch; d += 2) {
         const int t = t0 + d;
-        if (t < a.nframes) {  // wave-uniform
-            if (PAIR) st = g.p[d];
-            const uint32_t total =
-                pack_step(g.c[d], st, a.thr, thr2, byte_off, a.log_xs, a.log_diff, tile_log + run);
-            if (lane == 0 && MI355_ABLATE < 2) {
-                a.cnt[(size_t)t * a.ntiles + tile] = total;
-                a.logpos[(size_t)t * a.ntiles + tile] = run;
-            }
-            run += total;
+        if (t >= a.nframes) break;  // wave-uniform
+        const bool two = t + 1 < a.nframes;
+        // byte counts of the two frames share one register (16-bit fields: a wave total of
+        // 4*flags + 24 per lane is at most 64 * 88 = 5632) and one DPP reduction
+        uint32_t c0 = 24, c1 = 24;
+        if (PAIR) st = g.p[d];
+        const uint32_t run0 = run;
+        const uint64_t m0 = pack_step(g.c[d], st, tc, a.rec, run, tile, a.ntiles, c0);
+        run += (uint32_t)__builtin_popcountll(m0);
+        const uint32_t run1 = run;
+        uint64_t m1 = 0;
+        if (two) {
+            if (PAIR) st = g.p[d + 1];
+            m1 = pack_step(g.c[d + 1], st, tc, a.rec, run, tile, a.ntiles, c1);
+            run += (uint32_t)__builtin_popcountll(m1);
         }
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane(
+            wave_inclusive_scan((int)(c0 | (c1 << 16))), 63);
+        const uint32_t n0 = ((tot & 0xffffu) - 64u * 24u) >> 2, n1 = ((tot >> 16) - 64u * 24u) >> 2;
+        if (lane == d) meta = make_uint4((uint32_t)m0, (uint32_t)(m0 >> 32), n0, run0);
+        if (lane == d + 1) meta = make_uint4((uint32_t)m1, (uint32_t)(m1 >> 32), n1, run1);
     }
+    if (lane < kPrefetch && t0 + lane < a.nframes && MI355_ABLATE != 2 && MI355_ABLATE != 3)
+        a.meta[(size_t)(t0 + lane) * a.ntiles + tile] = meta;
 }
 
 template <bool PAIR, bool FAST>
@@ -183,8 +256,7 @@ __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint
     const int T = a.nframes;
     const uint8_t *cp = a.cur + byte_off;
     const uint8_t *pp = PAIR ? a.prev + byte_off : nullptr;
-    const size_t tile_log = (size_t)tile * a.log_cap;
-    const uint32_t thr2 = 2u * (uint32_t)a.thr;
+    const ThrConst tc{(127u - (uint32_t)a.thr) * 0x01010101u, (uint32_t)a.thr * 0x01010101u};
 
     uint4 st = make_uint4(0, 0, 0, 0);
     if (!PAIR) st = load16<FAST>(a.state + byte_off, valid);
@@ -193,15 +265,15 @@ __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint
     // flight; the next loads are issued right before the wait for the current ones, so the wait is an
     // exact s_waitcnt vmcnt(kPrefetch).
     Group<PAIR, FAST> ga, gb;
-    uint32_t run = 0;  // entries this tile has appended to its log so far
+    uint32_t run = 0;  // records this tile has appended to its log so far
     ga.load(a, cp, pp, 0, valid);
     for (int t0 = 0;;) {
         gb.load(a, cp, pp, t0 + kPrefetch, valid);
-        pack_group<PAIR, FAST>(a, ga, t0, st, run, tile, byte_off, tile_log, thr2, lane);
+        pack_group<PAIR, FAST>(a, ga, t0, st, run, tile, tc, lane);
         t0 += kPrefetch;
         if (t0 >= T) break;
         ga.load(a, cp, pp, t0 + kPrefetch, valid);
-        pack_group<PAIR, FAST>(a, gb, t0, st, run, tile, byte_off, tile_log, thr2, lane);
+        pack_group<PAIR, FAST>(a, gb, t0, st, run, tile, tc, lane);
         t0 += kPrefetch;
         if (t0 >= T) break;
     }
@@ -242,31 +314,33 @@ hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, hipStrea
 }
 
 // ---- scans ----------------------------------------------------------------------------------------
-// Block-wide exclusive scan of one value per thread (1024 threads = 16 waves).
-__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t *lds /*17*/,
-                                                              uint32_t &block_total) {
+// Block-wide exclusive scan of one value per thread (NW waves).
+template <int NW>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds /*NW+1*/,
+                                                         uint32_t &block_total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t incl = (uint32_t)wave_inclusive_scan((int)v);
     if (lane == 63) lds[wave] = incl;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t acc = 0;
-        for (int w = 0; w < 16; w++) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
             const uint32_t x = lds[w];
             lds[w] = acc;
             acc += x;
         }
-        lds[16] = acc;
+        lds[NW] = acc;
     }
     __syncthreads();
     const uint32_t r = lds[wave] + incl - v;
-    block_total = lds[16];
+    block_total = lds[NW];
     __syncthreads();
     return r;
 }
 
-// grid = T, block = 1024: segoff[t][*] = exclusive scan of cnt[t][*], totals[t] = sum.
-__global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t *cnt, uint32_t *segoff,
+// grid = T, block = 1024: segoff[t][*] = exclusive scan of the byte counts (meta.z), totals[t] = sum.
+__global__ __launch_bounds__(1024) void k_scan_tiles(const uint4 *meta, uint32_t *segoff,
                                                      uint32_t *totals, uint32_t ntiles) {
     __shared__ uint32_t lds[17];
     const size_t row = (size_t)blockIdx.x * ntiles;
@@ -274,14 +348,13 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t *cnt, uint32
     const uint32_t i0 = threadIdx.x * per;
     uint32_t sum = 0;
     for (uint32_t i = 0; i < per; i++)
-        if (i0 + i < ntiles) sum += cnt[row + i0 + i];
+        if (i0 + i < ntiles) sum += meta[row + i0 + i].z;
     uint32_t total;
-    uint32_t acc = block_exclusive_scan_1024(sum, lds, total);
+    uint32_t acc = block_exclusive_scan<16>(sum, lds, total);
     for (uint32_t i = 0; i < per; i++) {
         if (i0 + i < ntiles) {
-            const uint32_t c = cnt[row + i0 + i];
             segoff[row + i0 + i] = acc;
-            acc += c;
+            acc += meta[row + i0 + i].z;
         }
     }
     if (threadIdx.x == 0) totals[blockIdx.x] = total;
@@ -296,63 +369,187 @@ __global__ __launch_bounds__(1024) void k_scan_frames(const uint32_t *totals, ui
         const int t = base + (int)threadIdx.x;
         const uint32_t v = t < nframes ? totals[t] : 0u;
         uint32_t total;
-        const uint32_t ex = block_exclusive_scan_1024(v, lds, total);
+        const uint32_t ex = block_exclusive_scan<16>(v, lds, total);
         if (t < nframes) offsets[t] = carry + ex;
         carry += total;
     }
     if (threadIdx.x == 0) offsets[nframes] = carry;
 }
 
-hipError_t launch_scan(const uint32_t *cnt, uint32_t *segoff, uint32_t *totals, uint32_t ntiles,
+hipError_t launch_scan(const uint4 *meta, uint32_t *segoff, uint32_t *totals, uint32_t ntiles,
                        int nframes, uint32_t *offsets, hipStream_t s) {
-    hipLaunchKernelGGL(k_scan_tiles, dim3(nframes), dim3(1024), 0, s, cnt, segoff, totals, ntiles);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(nframes), dim3(1024), 0, s, meta, segoff, totals, ntiles);
     hipLaunchKernelGGL(k_scan_frames, dim3(1), dim3(1024), 0, s, totals, offsets, nframes);
     return hipGetLastError();
 }
 
-// ---- gather: log segments -> packed frame-major output ----------------------------------------------
-// grid = (ceil(ntiles/64), T), block = 256.  A workgroup owns 64 consecutive tiles of one frame; its
-// output range is contiguous, so the writes are fully coalesced.
-__global__ __launch_bounds__(256) void k_gather(const GatherArgs a) {
-    __shared__ uint32_t s_incl[kGatherTiles];
-    __shared__ uint32_t s_src[kGatherTiles];
-    const int t = blockIdx.y;
-    const uint32_t tile0 = blockIdx.x * kGatherTiles;
-    const size_t row = (size_t)t * a.ntiles;
+// ---- expand: records -> packed frame-major (xs, diff) -------------------------------------------------
+// grid = ceil(W/4), block = 256: like k_diff_pack, one wave owns one tile -- here it streams the tile's
+// record log, 64 consecutive records (one 1 KiB chunk, fully coalesced) per step with the next chunk
+// already in flight.  No workgroup barriers and no dependent global loads inside the loop: the
+// per-frame facts of the tile (log position, candidate ballot, output base = offsets[t] +
+// segoff[t][tile]) are staged once per 256 frames in a wave-private LDS table.  For its record the
+// lane finds the frame (binary search of the log position), the source lane (k-th set bit of the
+// ballot) and its slot inside the (frame, tile) segment (segmented scan of the byte counts, with a
+// carry for the frame that straddles two chunks), then writes its <= 16 entries.
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t v) {   // 0x80 per nonzero byte
+    return (((v & kL) + kL) | v) & kH;
+}
 
-    if (threadIdx.x < kGatherTiles) {  // exactly wave 0
-        const uint32_t tile = tile0 + threadIdx.x;
-        const uint32_t c = tile < a.ntiles ? a.cnt[row + tile] : 0u;
-        s_incl[threadIdx.x] = (uint32_t)wave_inclusive_scan((int)c);
-        s_src[threadIdx.x] = tile < a.ntiles ? a.logpos[row + tile] : 0u;
-    }
-    __syncthreads();
-    const uint32_t total = s_incl[kGatherTiles - 1];
-    if (total == 0) return;
-    const size_t dst0 = (size_t)a.offsets[t] + a.segoff[row + tile0];
-
-    for (uint32_t e = threadIdx.x; e < total; e += 256) {
-        // smallest sgm with s_incl[sgm] > e
-        uint32_t lo = 0, hi = kGatherTiles - 1;
+__device__ __forceinline__ int kth_set_bit(uint64_t mask, uint32_t k) {
+    uint32_t w = (uint32_t)mask;
+    int base = 0;
+    const uint32_t c = (uint32_t)__builtin_popcount(w);
+    if (k >= c) { k -= c; w = (uint32_t)(mask >> 32); base = 32; }
 #pragma unroll
-        for (int it = 0; it < 6; it++) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (s_incl[mid] > e) hi = mid; else lo = mid + 1;
+    for (int sh = 16; sh > 0; sh >>= 1) {
+        const uint32_t low = w & ((1u << sh) - 1u);
+        const uint32_t cl = (uint32_t)__builtin_popcount(low);
+        if (k >= cl) { k -= cl; w >>= sh; base += sh; } else { w = low; }
+    }
+    return base;
+}
+
+constexpr int kExpandFrames = 256;   // frames per LDS table block
+constexpr int kExpandGroup = 4;      // chunks per register group (two groups: 8 KiB in flight per wave)
+
+struct ExpandWave {      // per-wave state of k_expand
+    const uint32_t *recpos;   // LDS: log position of frame f (+ end sentinel)
+    const uint32_t *obase;    // LDS: output index of the (frame, tile) segment
+    const uint64_t *cmask;    // LDS: candidate ballot of frame f
+    uint32_t tile, nb, tb, p_begin, p_end;
+    uint32_t fcur;            // frame containing the first position of the current chunk
+    uint32_t last_t, last_bytes;   // frame cut by the previous chunk boundary and its bytes so far
+};
+
+// Loads are always issued (position clamped into the block's range): as in k_diff_pack the number
+// of vector-memory operations younger than a load must be a compile-time constant, or the compiler
+// degrades every wait to vmcnt(0).
+__device__ __forceinline__ uint4 expand_load(const ExpandArgs &a, const ExpandWave &w, uint32_t c,
+                                             int lane) {
+    uint32_t p = (c << 6) + (uint32_t)lane;
+    p = max(min(p, w.p_end - 1u), w.p_begin);
+    return a.rec[rec_index(p, w.tile, a.ntiles)];
+}
+
+__device__ __forceinline__ void expand_chunk(const ExpandArgs &a, ExpandWave &w, uint32_t c,
+                                             const uint4 rec, int lane) {
+    const uint32_t c0 = c << 6, p = c0 + (uint32_t)lane;
+    const bool act = p >= w.p_begin && p < w.p_end;
+    // frame of this record: the largest f with recpos[f] <= p.  A chunk overlaps only a few frames
+    // (a 1080p webcam tile appends ~19 records per frame), so every lane walks forward from the
+    // chunk's first frame; the walk is bounded by the table size.
+    uint32_t f = w.fcur;
+    if (act) {
+        while (f + 1u < w.nb && w.recpos[f + 1u] <= p) ++f;
+    }
+    const uint32_t last_lane = min(w.p_end, c0 + 64u) - c0 - 1u;   // last active lane
+    w.fcur = (uint32_t)__builtin_amdgcn_readlane((int)f, (int)last_lane);
+    const uint32_t fpos = w.recpos[f];
+    const int src_lane = act ? kth_set_bit(w.cmask[f], p - fpos) : 0;
+    // 16-bit map of the record's nonzero (= flagged) bytes: v_dot4 gathers the four 0x80 marks of a
+    // dword into 4 adjacent bits
+    uint32_t m16 = 0;
+    if (act) {
+        const uint32_t g0 = __builtin_amdgcn_udot4(nonzero_bytes(rec.x), 0x08040201u, 0u, false);
+        const uint32_t g1 = __builtin_amdgcn_udot4(nonzero_bytes(rec.y), 0x08040201u, 0u, false);
+        const uint32_t g2 = __builtin_amdgcn_udot4(nonzero_bytes(rec.z), 0x08040201u, 0u, false);
+        const uint32_t g3 = __builtin_amdgcn_udot4(nonzero_bytes(rec.w), 0x08040201u, 0u, false);
+        m16 = (g0 + (g1 << 4) + (g2 << 8) + (g3 << 12)) >> 7;
+    }
+    const uint32_t cnt = (uint32_t)__builtin_popcount(m16);
+    // segmented exclusive scan: bytes of earlier records of the same frame
+    const uint32_t incl = (uint32_t)wave_inclusive_scan((int)cnt);
+    const uint32_t seg_first = fpos > c0 ? fpos - c0 : 0u;   // lane where frame f starts
+    const uint32_t before = (uint32_t)__builtin_amdgcn_ds_bpermute(
+        (int)((seg_first ? seg_first - 1u : 0u) << 2), (int)incl);
+    uint32_t within = incl - cnt - (seg_first ? before : 0u);
+    const uint32_t tg = w.tb + f;
+    if (seg_first == 0 && tg == w.last_t) within += w.last_bytes;
+    // the frame cut by the end of this chunk carries its byte count into the next chunk
+    w.last_t = (uint32_t)__builtin_amdgcn_readlane((int)tg, (int)last_lane);
+    w.last_bytes = (uint32_t)__builtin_amdgcn_readlane((int)(within + cnt), (int)last_lane);
+
+    if (m16) {
+        uint32_t o = w.obase[f] + within;   // < 2^32: the batch total is below 2^32
+        const uint32_t byte_base = w.tile * kTileBytes + (uint32_t)src_lane * 16u;
+        do {
+            const int j = __builtin_ctz(m16);
+            m16 &= m16 - 1;
+            const uint32_t dw = j < 8 ? (j < 4 ? rec.x : rec.y) : (j < 12 ? rec.z : rec.w);
+            if (o < a.capacity) {
+                a.out_xs[o] = (int32_t)(byte_base + (uint32_t)j);          // kernels.cu:315
+                a.out_diff[o] = (uint8_t)(dw >> (8 * (j & 3)));            // kernels.cu:314
+            }
+            ++o;
+        } while (m16);
+    }
+}
+
+__device__ __forceinline__ void expand_group(const ExpandArgs &a, ExpandWave &w, uint32_t c,
+                                             const uint4 (&g)[kExpandGroup], int lane) {
+#pragma unroll
+    for (int d = 0; d < kExpandGroup; d++)
+        if (((c + (uint32_t)d) << 6) < w.p_end) expand_chunk(a, w, c + (uint32_t)d, g[d], lane);
+}
+
+__global__ __launch_bounds__(256) void k_expand(const ExpandArgs a, int nframes) {
+    __shared__ uint32_t s_recpos[kWavesPerBlock][kExpandFrames + 1];
+    __shared__ uint32_t s_base[kWavesPerBlock][kExpandFrames];
+    __shared__ uint64_t s_mask[kWavesPerBlock][kExpandFrames];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * kWavesPerBlock + wave;
+    if (tile >= a.ntiles) return;  // wave-uniform; the kernel has no workgroup barrier
+    uint32_t *recpos = s_recpos[wave];
+    uint32_t *obase = s_base[wave];
+    uint64_t *cmask = s_mask[wave];
+
+    ExpandWave w;
+    w.recpos = recpos; w.obase = obase; w.cmask = cmask;
+    w.tile = tile;
+    w.last_t = 0xffffffffu; w.last_bytes = 0;
+    for (int tb = 0; tb < nframes; tb += kExpandFrames) {
+        const int nb = min(kExpandFrames, nframes - tb);
+        __builtin_amdgcn_wave_barrier();
+        for (int f = lane; f < nb; f += 64) {
+            const size_t idx = (size_t)(tb + f) * a.ntiles + tile;
+            const uint4 m = a.meta[idx];
+            const uint64_t mk = (uint64_t)m.x | ((uint64_t)m.y << 32);
+            recpos[f] = m.w;
+            cmask[f] = mk;
+            obase[f] = a.offsets[tb + f] + a.segoff[idx];
+            if (f == nb - 1) recpos[nb] = m.w + (uint32_t)__builtin_popcountll(mk);
         }
-        const uint32_t sgm = lo;
-        const uint32_t before = sgm ? s_incl[sgm - 1] : 0u;
-        const size_t src = (size_t)(tile0 + sgm) * a.log_cap + s_src[sgm] + (e - before);
-        const size_t dst = dst0 + e;
-        if (dst < a.capacity) {
-            a.out_xs[dst] = a.log_xs[src];
-            a.out_diff[dst] = a.log_diff[src];
+        __builtin_amdgcn_wave_barrier();
+        w.nb = (uint32_t)nb; w.tb = (uint32_t)tb;
+        w.p_begin = recpos[0]; w.p_end = recpos[nb];
+        w.fcur = 0;
+        if (w.p_begin == w.p_end) continue;  // wave-uniform
+
+        // two register groups of kExpandGroup chunks, as in k_diff_pack: the next group's loads are
+        // issued right before the wait for the current one
+        uint4 ga[kExpandGroup], gb[kExpandGroup];
+        uint32_t c = w.p_begin >> 6;
+#pragma unroll
+        for (int d = 0; d < kExpandGroup; d++) ga[d] = expand_load(a, w, c + (uint32_t)d, lane);
+        for (;;) {
+#pragma unroll
+            for (int d = 0; d < kExpandGroup; d++) gb[d] = expand_load(a, w, c + kExpandGroup + (uint32_t)d, lane);
+            expand_group(a, w, c, ga, lane);
+            c += kExpandGroup;
+            if ((c << 6) >= w.p_end) break;
+#pragma unroll
+            for (int d = 0; d < kExpandGroup; d++) ga[d] = expand_load(a, w, c + kExpandGroup + (uint32_t)d, lane);
+            expand_group(a, w, c, gb, lane);
+            c += kExpandGroup;
+            if ((c << 6) >= w.p_end) break;
         }
     }
 }
 
-hipError_t launch_gather(const GatherArgs &a, int nframes, hipStream_t s) {
-    const dim3 grid((a.ntiles + kGatherTiles - 1) / kGatherTiles, nframes);
-    hipLaunchKernelGGL(k_gather, grid, dim3(256), 0, s, a);
+hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s) {
+    const dim3 grid((a.ntiles + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(k_expand, grid, dim3(64 * kWavesPerBlock), 0, s, a, nframes);
     return hipGetLastError();
 }
 

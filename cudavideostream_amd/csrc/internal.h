@@ -12,7 +12,6 @@ namespace mi355 {
 // (64 lanes x 16 B, a single global_load_dwordx4 per frame) for the whole batch.
 constexpr uint32_t kTileBytes = 1024;
 constexpr uint32_t kWavesPerBlock = 4;
-constexpr uint32_t kGatherTiles = 64;  // tiles per gather workgroup
 
 struct PackArgs {
     const uint8_t *cur;    // frame t at cur + t*stride
@@ -22,23 +21,17 @@ struct PackArgs {
     uint32_t n;            // bytes per frame
     int32_t nframes;       // T
     int32_t thr;           // threshold
-    uint32_t ntiles;       // ceil(n / 1024)
-    uint32_t log_cap;      // entries of log per tile (>= 1024 * T)
-    int32_t *log_xs;       // [ntiles][log_cap]
-    uint8_t *log_diff;     // [ntiles][log_cap]
-    uint32_t *cnt;         // [T][ntiles]  flagged bytes of (frame, tile)
-    uint32_t *logpos;      // [T][ntiles]  position of that segment inside the tile's log
+    uint32_t ntiles;       // W = ceil(n / 1024)
+    uint4 *rec;            // record log: T chunks x W tiles x 64 records of 16 masked diff bytes
+    uint4 *meta;           // [T][W]: {candidate ballot lo, hi, flagged bytes, log position}
 };
 
-struct GatherArgs {
-    const int32_t *log_xs;
-    const uint8_t *log_diff;
-    const uint32_t *cnt;      // [T][ntiles]
-    const uint32_t *logpos;   // [T][ntiles]
-    const uint32_t *segoff;   // [T][ntiles]  exclusive scan of cnt over tiles, per frame
-    const uint32_t *offsets;  // [T+1]        exclusive scan of the frame totals
+struct ExpandArgs {
+    const uint4 *rec;
+    const uint4 *meta;        // [T][W]
+    const uint32_t *segoff;   // [T][W]  exclusive scan of the byte counts over tiles, per frame
+    const uint32_t *offsets;  // [T+1]   exclusive scan of the frame totals
     uint32_t ntiles;
-    uint32_t log_cap;
     int32_t *out_xs;
     uint8_t *out_diff;
     size_t capacity;
@@ -46,9 +39,9 @@ struct GatherArgs {
 
 // diff_pack.hip
 hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, hipStream_t s);
-hipError_t launch_scan(const uint32_t *cnt, uint32_t *segoff, uint32_t *totals, uint32_t ntiles,
+hipError_t launch_scan(const uint4 *meta, uint32_t *segoff, uint32_t *totals, uint32_t ntiles,
                        int nframes, uint32_t *offsets, hipStream_t s);
-hipError_t launch_gather(const GatherArgs &a, int nframes, hipStream_t s);
+hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s);
 
 // filters.hip
 hipError_t launch_int_diff(const int32_t *cur, const int32_t *prev, int32_t *out, size_t n,

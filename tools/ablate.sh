@@ -1,16 +1,19 @@
 #!/bin/bash
-# Ablation of the pack kernel on the GPU box: builds libmi355diff variants with -DMI355_ABLATE=k into
-# gpurun_out/ablate/k/ and times each with tools/diffbench (outputs of k>0 are wrong by design; only the
-# kernel time matters).  Usage: bash tools/ablate.sh "0 1 2 3" [extra diffbench args]
+# A/B builds of libmi355diff on the GPU box (never shipped): every argument is "name:compiler flags";
+# each variant is compiled into gpurun_out/ablate/<name>/ and timed with tools/diffbench.
+#   bash tools/ablate.sh "base:" "nostore:-DMI355_ABLATE=1" "nont:-DMI355_NT_LOADS=0"
+# DIFFBENCH_ARGS adds harness arguments (e.g. "--batch 64").  Outputs of MI355_ABLATE>0 builds are
+# wrong by design; only the kernel time matters.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
-for k in $1; do
-  d=gpurun_out/ablate/$k; mkdir -p $d
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -DMI355_ABLATE=$k -shared \
+for v in "$@"; do
+  name=${v%%:*}; flags=${v#*:}
+  d=gpurun_out/ablate/$name; mkdir -p $d
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off $flags -shared \
       -o $d/libmi355diff.so cudavideostream_amd/csrc/core.hip cudavideostream_amd/csrc/diff_pack.hip cudavideostream_amd/csrc/filters.hip
   for rep in 1 2; do
-    echo -n "ablate=$k stream: "; LD_LIBRARY_PATH=$d timeout -k 5 120 tools/diffbench --steps 20 ${@:2}
+    echo -n "$name stream: "; LD_LIBRARY_PATH=$d timeout -k 5 120 tools/diffbench --steps 20 ${DIFFBENCH_ARGS:-}
   done
-  echo -n "ablate=$k pairs:  "; LD_LIBRARY_PATH=$d timeout -k 5 120 tools/diffbench --steps 20 --pairs ${@:2}
+  echo -n "$name pairs:  "; LD_LIBRARY_PATH=$d timeout -k 5 120 tools/diffbench --steps 20 --pairs ${DIFFBENCH_ARGS:-}
 done
