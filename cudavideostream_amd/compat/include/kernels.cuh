@@ -1,0 +1,48 @@
+// compat/include/kernels.cuh -- diff::cuda::CUDACore, the MI355X drop-in.
+//
+// Same class name, namespace and public member functions as the reference's
+// server/include/kernels.cuh:13-43, so the reference's server.cpp / threads.cpp link against it
+// unchanged (same mangled names).  The reference constructs the object BY VALUE on the caller's stack
+// (server/src/server.cpp:53) using its own header, so the object size here must not exceed the
+// reference's: the private part is one handle plus padding up to the reference's 160 bytes (LP64)
+// instead of the reference's device pointers.  oracle/ref_harness/layout_check.cpp verifies the size
+// against the reference header whenever the reference tree is present.
+#ifndef MI355_COMPAT_KERNELS_CUH_
+#define MI355_COMPAT_KERNELS_CUH_
+
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+
+#include "utils.hpp"
+
+struct mi355_core;
+
+namespace diff {
+namespace cuda {
+
+class CUDACore {
+private:
+    mi355_core *core_;          // the C-ABI handle (include/mi355diff.h)
+    int total_;
+    int reserved_int_;
+    unsigned char reserved_[144];
+
+public:
+    // kernels.cu:377-428: uploads the glyph atlas, the convolution kernel and the base frame.
+    CUDACore(uint8_t *charsPx, diff::utils::matsz &charsSz, float *k, int total, uint8_t *sampleMatData,
+             diff::utils::matsz &frameSz);
+    // kernels.cu:531-536: pinned host buffers (three frames of 3rc bytes + slack, one int[3rc] + slack).
+    static void alloc_arrays(uint8_t **h_frame, uint8_t **n_frame, uint8_t **o_frame, int **h_xs, int r, int c);
+    // kernels.cu:430-525: one frame in (frameData), diff/xs/count (+ visualisation frame) out.
+    void exec_core(uint8_t *frameData, uint8_t *showReadyNData, std::string &text, unsigned int *h_pos,
+                   int *h_xs);
+    // kernels.cu:527-529
+    size_t chunkt_size();
+};
+
+static_assert(sizeof(CUDACore) == 160, "must match the reference's object size (LP64)");
+
+}  // namespace cuda
+}  // namespace diff
+#endif

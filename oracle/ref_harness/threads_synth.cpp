@@ -63,12 +63,12 @@ ThreadsCore::ThreadsCore() {
     c->w = hdr[0]; c->h = hdr[1]; c->nframes = hdr[2];
     c->total = (size_t)3 * c->w * c->h;
     this->frameSz = diff::utils::matsz(c->h, c->w);
-    // glyph atlas: the overlay text starts empty and this harness never runs long enough for the
-    // 1 Hz statistics string to appear, so a zeroed 22-glyph atlas of a plausible size is enough.
-    this->charSz = diff::utils::matsz(32, 32);
-    size_t atlas = (size_t)22 * 3 * this->charSz.area();
-    this->charsPx = new uint8_t[atlas];
-    memset(this->charsPx, 0, atlas);
+    // No glyph atlas (size 0x0): the reference's 1 Hz statistics string (server.cpp:151-171) may or
+    // may not appear during a short run, and without glyphs the overlay is a no-op either way, so the
+    // outputs stay deterministic.  The overlay itself is covered by tests/test_filters_gpu.py.
+    this->charSz = diff::utils::matsz(0, 0);
+    this->charsPx = new uint8_t[16];
+    memset(this->charsPx, 0, 16);
 #ifdef SYNTH_HIP
     diff::cuda::CUDACore::alloc_arrays(&c->frame, &c->vis, &c->spare, &c->xs, c->h, c->w);
 #else

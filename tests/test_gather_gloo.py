@@ -1,0 +1,96 @@
+"""world_size-2 (and 3) CPU rehearsal of the multi-GPU exchange step (cudavideostream_amd/gather.py)
+over the gloo backend: every rank owns an independent stream, the per-frame index and the
+changed-pixel payload are gathered to rank 0 and must equal the ranks' oracle outputs concatenated
+in rank order -- the same code path bench.py runs over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cudavideostream_amd import gather as gx
+from cudavideostream_amd import synth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_stream(rank, T, w, h):
+    from oracle import pyoracle as po
+    base, frames = synth.webcam_stream(T, w, h, seed=21 + rank)
+    if rank == 1:
+        frames = frames.copy()
+        frames[1] = base          # a frame with (almost) nothing to send
+    return po.diff_stream(frames, base)
+
+
+def _worker(rank, world, port, T, w, h, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        off, xs, df, _ = _rank_stream(rank, T, w, h)
+        cap = xs.size + 100
+        t_off = torch.from_numpy(off.view(np.int32).copy())
+        t_xs = torch.zeros(cap, dtype=torch.int32); t_xs[:xs.size] = torch.from_numpy(xs)
+        t_df = torch.zeros(cap, dtype=torch.uint8); t_df[:df.size] = torch.from_numpy(df)
+        idx = gx.gather_index(t_off, dst=0)
+        totals, xs_all, df_all, index = gx.gather_payload(t_off, t_xs, t_df, dst=0)
+        if rank == 0:
+            q.put((idx.numpy().copy(), totals, xs_all.numpy().copy(), df_all.numpy().copy(),
+                   index.numpy().copy()))
+        else:
+            assert idx is None and xs_all is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_payload_and_index(world):
+    T, w, h = 4, 48, 32
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, T, w, h, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    idx, totals, xs_all, df_all, index = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    exp = [_rank_stream(r, T, w, h) for r in range(world)]
+    assert totals == [int(e[0][-1]) for e in exp]
+    assert np.array_equal(idx.view(np.uint32), np.stack([e[0] for e in exp]))
+    assert np.array_equal(index, idx)
+    assert np.array_equal(xs_all, np.concatenate([e[1] for e in exp]))
+    assert np.array_equal(df_all, np.concatenate([e[2] for e in exp]))
+    # rank r's frame t is recoverable from the gathered buffers alone
+    at = 0
+    for r in range(world):
+        off = exp[r][0].astype(np.int64)
+        for t in range(T):
+            seg = slice(at + off[t], at + off[t + 1])
+            assert np.array_equal(xs_all[seg], exp[r][1][off[t]:off[t + 1]])
+        at += totals[r]
+
+
+def test_single_process_passthrough():
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        off = torch.tensor([0, 2, 5], dtype=torch.int32)
+        xs = torch.arange(8, dtype=torch.int32)
+        df = torch.arange(8, dtype=torch.uint8)
+        totals, a, b, index = gx.gather_payload(off, xs, df)
+        assert totals == [5] and a.tolist() == [0, 1, 2, 3, 4] and b.tolist() == [0, 1, 2, 3, 4]
+        assert gx.gather_index(off).shape == (1, 3)
+    finally:
+        dist.destroy_process_group()
