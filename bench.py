@@ -41,34 +41,24 @@ def parse():
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--gather", choices=["every", "last", "index", "none"], default="last")
-    p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-pair", action="store_true")
+    p.add_argument("--no-host-path", action="store_true")
     return p.parse_args()
 
 
 def cpu_baseline(args, base, frames, dev):
-    """Oracle (CPU restatement of tests/cuda_streaming/test.cu:560-576) on a bounded sample of the
-    same stream, single-threaded like the reference's elaboration thread; also the parity check of
-    the GPU path on that sample."""
+    """Oracle (CPU restatement of tests/cuda_streaming/test.cu:560-576) timed on a bounded sample of
+    the same workload, single-threaded like the reference's one elaboration thread (the frames of the
+    batch, cycled with the state carried along, for about --cpu-seconds); also the parity check of the
+    GPU path on the first frames of the stream."""
     from oracle import pyoracle as po
-    n = base.numel()
+    B = frames.shape[0]
     h_base = base.cpu().numpy()
-    f0 = frames[0].cpu().numpy()
-    t = time.perf_counter()
-    po.diff_pack(f0, h_base)
-    t_one = max(time.perf_counter() - t, 1e-4)
-    S = int(max(4, min(frames.shape[0], 96, args.cpu_seconds / t_one)))
-    h_frames = frames[:S].cpu().numpy()
-    t = time.perf_counter()
-    eo, exs, edf, est = po.diff_stream(h_frames, h_base)
-    dt = time.perf_counter() - t
-    ncores = os.cpu_count() or 1
-    st = h_base.copy()
-    t = time.perf_counter()
-    for i in range(min(S, 16)):
-        _, _, _, st = po.diff_pack_mt(h_frames[i], st, nthreads=ncores)
-    dt_mt = (time.perf_counter() - t) / min(S, 16)
+    h_frames = frames.cpu().numpy()
+    S = min(B, 64)
+    eo, exs, edf, est = po.diff_stream(h_frames[:S], h_base)
     # parity of the product path on the same sample
     with CUDACore(args.width, args.height, max_batch=S) as c2:
         c2.use_torch_stream()
@@ -83,11 +73,35 @@ def cpu_baseline(args, base, frames, dev):
               and np.array_equal(d_xs[:int(eo[-1])].cpu().numpy(), exs)
               and np.array_equal(d_df[:int(eo[-1])].cpu().numpy(), edf)
               and np.array_equal(c2.get_state(), est))
-    base_obj = {"value": round(S / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-                "sample": f"first {S} frames of the same {args.width}x{args.height} S1 stream, "
-                          f"oracle/cpu_ref.c ora_diff_stream, {dt:.2f} s",
-                "all_cores": {"value": round(1.0 / dt_mt, 2), "unit": "frames/s", "cores": ncores,
-                              "sample": f"{min(S, 16)} frames, row-band pthreads"}}
+    # timing: single thread
+    L = po.lib()
+    n = h_base.size
+    st = h_base.copy()
+    xs = np.empty(n, np.int32)
+    df = np.empty(n, np.uint8)
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < args.cpu_seconds:
+        for t in range(B):
+            L.ora_diff_pack(h_frames[t], st, n, 20, xs, df)
+        done += B
+    dt = time.perf_counter() - t0
+    # timing: all host cores (row bands, identical output)
+    ncores = os.cpu_count() or 1
+    nthr = min(ncores, 32)
+    st = h_base.copy()
+    done_mt, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < min(3.0, args.cpu_seconds):
+        for t in range(min(B, 32)):
+            L.ora_diff_pack_mt(h_frames[t], st, n, 20, xs, df, nthr)
+        done_mt += min(B, 32)
+    dt_mt = time.perf_counter() - t0
+    base_obj = {"value": round(done / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": f"{done} frames ({done // B} passes over the batch's {B} frames of the same "
+                          f"{args.width}x{args.height} S1 stream, state carried), oracle/cpu_ref.c "
+                          f"ora_diff_pack, {dt:.1f} s",
+                "all_cores": {"value": round(done_mt / dt_mt, 2), "unit": "frames/s", "cores": nthr,
+                              "host_cores": ncores,
+                              "sample": f"{done_mt} frames, row-band pthreads, {dt_mt:.1f} s"}}
     return base_obj, bool(ok)
 
 
@@ -196,6 +210,8 @@ def main():
         }
         if world == 1 and not args.no_pair:
             out["pair_mode"] = pair_mode(args, core, frames, d_off, d_xs, d_df, cap, n)
+        if world == 1 and not args.no_host_path:
+            out["host_path"] = host_path(args, base, frames)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"], out["parity"] = cpu_baseline(args, base, frames, dev)
         else:
@@ -207,20 +223,48 @@ def main():
         dist.destroy_process_group()
 
 
+def host_path(args, base, frames, reps=60):
+    """Secondary line, never `value`: the reference's per-frame entry point exec_core (kernels.cu:430-525)
+    through mi355_exec with pinned host buffers -- H2D of the frame, kernels, D2H of count/diff/xs and the
+    two synchronisations of the reference.  PCIe/latency-bound."""
+    n = base.numel()
+    with CUDACore(args.width, args.height, sample_mat_data=base.cpu().numpy()) as c:
+        h_frame, n_frame, o_frame, h_xs = CUDACore.alloc_arrays(args.height, args.width)
+        src = frames[:min(frames.shape[0], 16)].cpu().numpy()
+        for i in range(5):
+            h_frame.array[:n] = src[i % src.shape[0]]
+            c.exec_core(h_frame.array, None, "", h_xs.array)
+        copy_s = 0.0
+        t0 = time.perf_counter()
+        for i in range(reps):
+            tc = time.perf_counter()
+            h_frame.array[:n] = src[i % src.shape[0]]   # stands in for the capture thread's write
+            copy_s += time.perf_counter() - tc
+            c.exec_core(h_frame.array, None, "", h_xs.array)
+        dt = time.perf_counter() - t0 - copy_s
+        for a in (h_frame, n_frame, o_frame, h_xs):
+            a.free()
+    return {"frames_per_s": round(reps / dt, 1), "ms_per_frame": round(dt / reps * 1e3, 4),
+            "note": "mi355_exec per frame: H2D frame + kernels + D2H count/diff/xs, 2 syncs (PCIe-inclusive)"}
+
+
 def pair_mode(args, core, frames, d_off, d_xs, d_df, cap, n):
-    """Secondary line: stateless frame pairs (cur = frame t, prev = frame t-1), i.e. 2N bytes of HBM
-    reads per frame with no reuse -- the plain streaming rate of the same kernel."""
-    B = frames.shape[0] - 1
+    """Secondary line: stateless frame pairs with NO reuse between the two operands (cur = first half
+    of the resident frames, prev = second half), i.e. 2N bytes of HBM reads per frame -- the plain
+    streaming rate of the same kernels.  (The halves show different rectangle positions, so P is larger
+    than in the stream.)"""
+    B = frames.shape[0] // 2
+    cur, prev = frames[:B], frames[B:2 * B]
     core.set_timing(True)
     core.reset_timing()
     for _ in range(3):
-        core.diff_pairs_batch(frames[1:], frames[:-1], B, d_off, d_xs, d_df, cap)
+        core.diff_pairs_batch(cur, prev, B, d_off, d_xs, d_df, cap)
     torch.cuda.synchronize()
     core.reset_timing()
-    reps = 10
+    reps = 20
     t0 = time.perf_counter()
     for _ in range(reps):
-        core.diff_pairs_batch(frames[1:], frames[:-1], B, d_off, d_xs, d_df, cap)
+        core.diff_pairs_batch(cur, prev, B, d_off, d_xs, d_df, cap)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms_pack, _, launches = core.get_timing()
@@ -228,7 +272,7 @@ def pair_mode(args, core, frames, d_off, d_xs, d_df, cap, n):
     p = int(d_off.cpu().numpy().view(np.uint32)[B])
     pack_ms = ms_pack / max(launches, 1)
     alg = 2.0 * n * B + 5.0 * p
-    return {"frames_per_s": round(B * reps / dt, 1), "kernel_ms": round(pack_ms, 4),
+    return {"frames_per_s": round(B * reps / dt, 1), "frames_per_launch": B, "kernel_ms": round(pack_ms, 4),
             "achieved_gbps": round(alg / (pack_ms * 1e-3) / 1e9, 1),
             "frac": round(alg / (pack_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "changed_bytes_per_frame": round(p / B, 1)}

@@ -12,7 +12,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="bench.py --steps $STEPS --warmup 2 --no-cpu --no-pair"
+ARGS="bench.py --steps $STEPS --warmup 2 --no-cpu --no-pair --no-host-path"
 cd $ROOT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || echo "trace failed"
 # counter passes run the C++ harness (same workload, same library): rocprofv3's counter collection

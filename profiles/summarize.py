@@ -44,10 +44,15 @@ if trace:
     per = defaultdict(list)
     for r in kernel_rows(trace):
         per[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    lines = []
     for k, v in per.items():
         if "mi355" in k:
             v2 = sorted(v)
-            print(f"trace {k[:50]}: n={len(v)} avg={sum(v)/len(v)/1e3:.1f}us med={v2[len(v2)//2]/1e3:.1f}us")
+            lines.append(f"{k[:60]}: launches={len(v)} avg={sum(v)/len(v)/1e3:.1f}us med={v2[len(v2)//2]/1e3:.1f}us "
+                         f"min={v2[0]/1e3:.1f}us max={v2[-1]/1e3:.1f}us")
+    print("\n".join(lines))
+    open(os.path.join(here, f"{tag}_kernel_trace_summary.txt"), "w").write(
+        "rocprofv3 --kernel-trace, per-kernel launch durations (bench.py --steps N --warmup 2)\n" + "\n".join(lines) + "\n")
 
 pmc = {}
 for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
