@@ -5,8 +5,8 @@
 // unchanged (same mangled names).  The reference constructs the object BY VALUE on the caller's stack
 // (server/src/server.cpp:53) using its own header, so the object size here must not exceed the
 // reference's: the private part is one handle plus padding up to the reference's 160 bytes (LP64)
-// instead of the reference's device pointers.  oracle/ref_harness/layout_check.cpp verifies the size
-// against the reference header whenever the reference tree is present.
+// instead of the reference's device pointers.  The test harness's layout check
+// verifies the size against the reference header whenever the reference tree is present.
 #ifndef MI355_COMPAT_KERNELS_CUH_
 #define MI355_COMPAT_KERNELS_CUH_
 

@@ -100,8 +100,13 @@ class CUDACore:
         return self._lib.mi355_workspace_bytes(self._h)
 
     def use_torch_stream(self):
+        """Enqueue on PyTorch's current stream (0 = the default stream), so torch ops, events and
+        collectives issued on it are ordered with the core's kernels."""
         import torch
-        _l.check(self._lib.mi355_set_stream(self._h, torch.cuda.current_stream().cuda_stream))
+        _l.check(self._lib.mi355_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def use_own_stream(self):
+        _l.check(self._lib.mi355_use_own_stream(self._h))
 
     def synchronize(self):
         _l.check(self._lib.mi355_synchronize(self._h))
@@ -184,6 +189,12 @@ class CUDACore:
 
     def conv3x3(self, d_in, d_out):
         _l.check(self._lib.mi355_conv3x3(self._h, _ptr(d_in), _ptr(d_out)))
+
+    def filter_batch(self, op, d_in, d_out, nframes, d_in2=None, stride=None):
+        """Batched per-frame filter (lib.OP_*): one launch per kernel for nframes frames."""
+        stride = self.total if stride is None else stride
+        _l.check(self._lib.mi355_filter_batch(self._h, int(op), _ptr(d_in), _ptr(d_in2), _ptr(d_out), stride,
+                                              nframes))
 
     # -- measurement ------------------------------------------------------------------------------
     def set_timing(self, on):

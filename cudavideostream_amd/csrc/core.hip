@@ -10,7 +10,7 @@
 //   meta      T*W*16       per (frame, tile): candidate ballot, flagged-byte count, log position
 //   segoff    T*W*4;  totals T*4;  offsets (T+1)*4
 //   one_xs N*4, one_diff N exec(): packed output of a single frame before the D2H copies
-//   hist 256*4, thr 4, k9 9*4, heat LUT 766*3, glyph atlas
+//   hist T*256*4, thr T*4 (per frame of a filter batch), k9 9*4, heat LUT 766*3, glyph atlas
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -231,8 +231,8 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (!rc) rc = dev_alloc(c, &c->offsets, T + 1);
     if (!rc) rc = dev_alloc(c, &c->one_xs, N + 4);
     if (!rc) rc = dev_alloc(c, &c->one_diff, N + 16);
-    if (!rc) rc = dev_alloc(c, &c->hist, 256);
-    if (!rc) rc = dev_alloc(c, &c->thr, 1);
+    if (!rc) rc = dev_alloc(c, &c->hist, 256 * T);
+    if (!rc) rc = dev_alloc(c, &c->thr, T);
     if (!rc) rc = dev_alloc(c, &c->k9, 9);
     if (!rc) rc = dev_alloc(c, &c->lut, 768 * 3);
     if (!rc) { e = hipHostMalloc((void **)&c->h_count, 2 * sizeof(uint32_t), hipHostMallocDefault); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipHostMalloc", e); }
@@ -268,7 +268,15 @@ int mi355_set_stream(mi355_core *c, void *hip_stream) {
     if (!c) return fail(MI355_ERR_INVALID, "null core");
     if (int rc = use_device(c)) return rc;
     if (int rc = harvest_timing(c)) return rc;
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->stream = (hipStream_t)hip_stream;  // NULL is the (legacy) default stream, a valid choice
+    return MI355_OK;
+}
+
+int mi355_use_own_stream(mi355_core *c) {
+    if (!c) return fail(MI355_ERR_INVALID, "null core");
+    if (int rc = use_device(c)) return rc;
+    if (int rc = harvest_timing(c)) return rc;
+    c->stream = c->own_stream;
     return MI355_OK;
 }
 
@@ -342,14 +350,14 @@ int mi355_int_diff(mi355_core *c, const void *d_cur, const void *d_prev, void *d
 int mi355_gray_avg(mi355_core *c, const void *d_in, void *d_out) {
     if (!c || (c->n && (!d_in || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
     if (int rc = use_device(c)) return rc;
-    HIP_TRY(launch_gray((const uint8_t *)d_in, (uint8_t *)d_out, c->n / 3, false, c->stream));
+    HIP_TRY(launch_gray((const uint8_t *)d_in, (uint8_t *)d_out, c->n / 3, false, FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
 }
 
 int mi355_gray_weighted(mi355_core *c, const void *d_in, void *d_out) {
     if (!c || (c->n && (!d_in || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
     if (int rc = use_device(c)) return rc;
-    HIP_TRY(launch_gray((const uint8_t *)d_in, (uint8_t *)d_out, c->n / 3, true, c->stream));
+    HIP_TRY(launch_gray((const uint8_t *)d_in, (uint8_t *)d_out, c->n / 3, true, FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
 }
 
@@ -358,7 +366,7 @@ int mi355_binarize_chain(mi355_core *c, const void *d_gray, void *d_out, void *d
     if (int rc = use_device(c)) return rc;
     int32_t *hist = d_hist ? (int32_t *)d_hist : c->hist;
     int32_t *thr = d_thr ? (int32_t *)d_thr : c->thr;
-    HIP_TRY(launch_binarize_chain((const uint8_t *)d_gray, (uint8_t *)d_out, c->n, hist, thr, c->stream));
+    HIP_TRY(launch_binarize_chain((const uint8_t *)d_gray, (uint8_t *)d_out, c->n, hist, thr, FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
 }
 
@@ -366,7 +374,7 @@ int mi355_heat_map(mi355_core *c, const void *d_cur, const void *d_prev, void *d
     if (!c || (c->n && (!d_cur || !d_prev || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
     if (int rc = use_device(c)) return rc;
     HIP_TRY(launch_heat_map((const uint8_t *)d_cur, (const uint8_t *)d_prev, (uint8_t *)d_out, c->n / 3,
-                            c->lut, c->stream));
+                            c->lut, FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
 }
 
@@ -374,7 +382,7 @@ int mi355_red_dense(mi355_core *c, const void *d_cur, const void *d_prev, void *
     if (!c || (c->n && (!d_cur || !d_prev || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
     if (int rc = use_device(c)) return rc;
     HIP_TRY(launch_red_dense((const uint8_t *)d_cur, (const uint8_t *)d_prev, (uint8_t *)d_out, c->n / 3,
-                             c->cfg.threshold, c->stream));
+                             c->cfg.threshold, FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
 }
 
@@ -392,7 +400,39 @@ int mi355_conv3x3(mi355_core *c, const void *d_in, void *d_out) {
     if (!c->have_k9) return fail(MI355_ERR_STATE, "mi355_set_conv_kernel not called");
     if (int rc = use_device(c)) return rc;
     HIP_TRY(launch_conv3x3((const uint8_t *)d_in, (uint8_t *)d_out, c->cfg.width, c->cfg.height, c->k9,
-                           c->stream));
+                           FrameBatch{c->n, 1}, c->stream));
+    return MI355_OK;
+}
+
+int mi355_filter_batch(mi355_core *c, int op, const void *d_in, const void *d_in2, void *d_out,
+                       size_t stride_bytes, int nframes) {
+    if (!c) return fail(MI355_ERR_INVALID, "null core");
+    if (nframes < 0 || nframes > c->cfg.max_batch) return fail(MI355_ERR_INVALID, "nframes outside [0, max_batch]");
+    if (nframes == 0 || c->n == 0) return MI355_OK;
+    if (!d_in || !d_out) return fail(MI355_ERR_INVALID, "null frame pointer");
+    if (stride_bytes < c->n) return fail(MI355_ERR_INVALID, "stride_bytes < frame bytes");
+    const bool two = op == MI355_OP_HEAT_MAP || op == MI355_OP_RED_DENSE;
+    if (two && !d_in2) return fail(MI355_ERR_INVALID, "this filter needs the previous frames (d_in2)");
+    if (op == MI355_OP_CONV3X3 && !c->have_k9) return fail(MI355_ERR_STATE, "mi355_set_conv_kernel not called");
+    if (op == MI355_OP_CONV3X3 && d_in == d_out) return fail(MI355_ERR_INVALID, "conv3x3 cannot run in place");
+    if (int rc = use_device(c)) return rc;
+    const uint8_t *in = (const uint8_t *)d_in, *in2 = (const uint8_t *)d_in2;
+    uint8_t *out = (uint8_t *)d_out;
+    const FrameBatch fb{stride_bytes, nframes};
+    const uint32_t npix = c->n / 3;
+    switch (op) {
+        case MI355_OP_GRAY_AVG: HIP_TRY(launch_gray(in, out, npix, false, fb, c->stream)); break;
+        case MI355_OP_GRAY_WEIGHTED: HIP_TRY(launch_gray(in, out, npix, true, fb, c->stream)); break;
+        case MI355_OP_BINARIZE: HIP_TRY(launch_binarize_chain(in, out, c->n, c->hist, c->thr, fb, c->stream)); break;
+        case MI355_OP_GRAY_AVG_BINARIZE:
+            HIP_TRY(launch_gray_binarize_fused(in, out, npix, false, c->hist, c->thr, fb, c->stream)); break;
+        case MI355_OP_GRAY_WEIGHTED_BINARIZE:
+            HIP_TRY(launch_gray_binarize_fused(in, out, npix, true, c->hist, c->thr, fb, c->stream)); break;
+        case MI355_OP_HEAT_MAP: HIP_TRY(launch_heat_map(in, in2, out, npix, c->lut, fb, c->stream)); break;
+        case MI355_OP_RED_DENSE: HIP_TRY(launch_red_dense(in, in2, out, npix, c->cfg.threshold, fb, c->stream)); break;
+        case MI355_OP_CONV3X3: HIP_TRY(launch_conv3x3(in, out, c->cfg.width, c->cfg.height, c->k9, fb, c->stream)); break;
+        default: return fail(MI355_ERR_INVALID, "unknown filter op");
+    }
     return MI355_OK;
 }
 
@@ -406,11 +446,12 @@ int mi355_exec(mi355_core *c, uint8_t *frame_data, uint8_t *show_ready, const ch
     if (int rc = use_device(c)) return rc;
     hipStream_t s = c->stream;
     const uint32_t N = c->n, npix = N / 3;
+    const FrameBatch one{N, 1};
 
     // kernels.cu:457-462  H2D (+ convolution when NOISE_FILTER)
     if (c->cfg.noise_filter) {
         HIP_TRY(hipMemcpyAsync(c->aux, frame_data, N, hipMemcpyHostToDevice, s));
-        HIP_TRY(launch_conv3x3(c->aux, c->in, c->cfg.width, c->cfg.height, c->k9, s));
+        HIP_TRY(launch_conv3x3(c->aux, c->in, c->cfg.width, c->cfg.height, c->k9, one, s));
     } else {
         HIP_TRY(hipMemcpyAsync(c->in, frame_data, N, hipMemcpyHostToDevice, s));
     }
@@ -427,12 +468,13 @@ int mi355_exec(mi355_core *c, uint8_t *frame_data, uint8_t *show_ready, const ch
     }
     // kernels.cu:478-502  visualisers that look at the frame before the diff
     if (vis == MI355_VIS_HEAT) {
-        HIP_TRY(launch_heat_map(c->in, c->state, c->vis, npix, c->lut, s));
+        HIP_TRY(launch_heat_map(c->in, c->state, c->vis, npix, c->lut, one, s));
     } else if (vis == MI355_VIS_GRAY) {
-        HIP_TRY(launch_gray(c->in, c->vis, npix, true, s));
+        HIP_TRY(launch_gray(c->in, c->vis, npix, true, one, s));
     } else if (vis == MI355_VIS_BINARIZE) {
-        HIP_TRY(launch_gray(c->in, c->aux, npix, true, s));
-        HIP_TRY(launch_binarize_chain(c->aux, c->vis, N, c->hist, c->thr, s));
+        // grayscale_kernel_v3 + histogram + compute_max + binarize (kernels.cu:493-498), fused: the
+        // gray frame is never materialised
+        HIP_TRY(launch_gray_binarize_fused(c->in, c->vis, npix, true, c->hist, c->thr, one, s));
     } else if (vis == MI355_VIS_RED_OVERLAP) {
         // kernels.cu:517 paints onto d_previous, i.e. the state *before* this frame's feedback
         HIP_TRY(hipMemcpyAsync(c->vis, c->state, N, hipMemcpyDeviceToDevice, s));

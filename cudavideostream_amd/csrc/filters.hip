@@ -99,8 +99,11 @@ __device__ __forceinline__ uint32_t gray_of(uint32_t b, uint32_t g, uint32_t r) 
     return (b + g + r) / 3u;
 }
 
+// Batched launches: blockIdx.y is the frame, frame f lives at base + f*stride.
 template <bool WEIGHTED, bool FAST>
-__global__ __launch_bounds__(256) void k_gray(const uint8_t *in, uint8_t *out, uint32_t npix) {
+__global__ __launch_bounds__(256) void k_gray(const uint8_t *in, uint8_t *out, uint32_t npix, size_t stride) {
+    in += (size_t)blockIdx.y * stride;
+    out += (size_t)blockIdx.y * stride;
     const uint32_t lane_px = (blockIdx.x * 256u + threadIdx.x) * 16u;
     if (lane_px >= npix) return;
     const uint32_t rem = npix - lane_px;
@@ -128,42 +131,76 @@ __global__ __launch_bounds__(256) void k_gray(const uint8_t *in, uint8_t *out, u
     }
 }
 
-hipError_t launch_gray(const uint8_t *in, uint8_t *out, uint32_t npix, bool weighted, hipStream_t s) {
-    if (npix == 0) return hipSuccess;
-    const bool fast = aligned16(in) && aligned16(out);
-    const dim3 g = px16_grid(npix), b(256);
+hipError_t launch_gray(const uint8_t *in, uint8_t *out, uint32_t npix, bool weighted, FrameBatch fb,
+                       hipStream_t s) {
+    if (npix == 0 || fb.nframes <= 0) return hipSuccess;
+    const bool fast = aligned16(in) && aligned16(out) && fb.stride % 16 == 0;
+    dim3 g = px16_grid(npix);
+    g.y = (unsigned)fb.nframes;
+    const dim3 b(256);
     if (weighted) {
-        if (fast) hipLaunchKernelGGL((k_gray<true, true>), g, b, 0, s, in, out, npix);
-        else hipLaunchKernelGGL((k_gray<true, false>), g, b, 0, s, in, out, npix);
+        if (fast) hipLaunchKernelGGL((k_gray<true, true>), g, b, 0, s, in, out, npix, fb.stride);
+        else hipLaunchKernelGGL((k_gray<true, false>), g, b, 0, s, in, out, npix, fb.stride);
     } else {
-        if (fast) hipLaunchKernelGGL((k_gray<false, true>), g, b, 0, s, in, out, npix);
-        else hipLaunchKernelGGL((k_gray<false, false>), g, b, 0, s, in, out, npix);
+        if (fast) hipLaunchKernelGGL((k_gray<false, true>), g, b, 0, s, in, out, npix, fb.stride);
+        else hipLaunchKernelGGL((k_gray<false, false>), g, b, 0, s, in, out, npix, fb.stride);
     }
     return hipGetLastError();
 }
 
 // ---- binarize chain: kernels.cu:138-241, CPU semantics server/src/server.cpp:103-135 -----------------
-// Histogram of every 3rd byte (one sample per pixel): per-wave private LDS bins, merged per workgroup,
-// then 256 global atomics per workgroup (integer adds: order-independent, deterministic).
-__global__ __launch_bounds__(256) void k_histogram(const uint8_t *gray3, uint32_t npix, int32_t *hist,
-                                                   uint32_t px_per_block) {
-    __shared__ int32_t bins[4][256];
-    for (int i = threadIdx.x; i < 1024; i += 256) (&bins[0][0])[i] = 0;
+// Histogram of one sample per pixel: 16 pixels (48 B) per lane per step, 8 private LDS copies of the
+// bins per wave (flat image areas would otherwise serialise 64 lanes on one bin), merged per
+// workgroup, then 256 global atomics per 16384 pixels (integer adds: order-independent).  MODE 0 reads the gray
+// value replicated in a gray3 frame (every 3rd byte, server.cpp:104); MODE 1/2 read the COLOUR frame
+// and compute the gray value on the fly (fused chain: no gray frame is materialised).
+constexpr int kHistReplicas = 8;    // private copies of the 256 bins per wave (lane & 7)
+constexpr int kHistBlocks = 4;      // 16-pixel x 256-lane blocks per workgroup (16384 pixels)
+
+template <int MODE /*0: gray3 in, 1: colour in + avg, 2: colour in + weighted*/, bool FAST>
+__global__ __launch_bounds__(256) void k_histogram(const uint8_t *img, uint32_t npix, int32_t *hist,
+                                                   size_t stride) {
+    __shared__ int32_t bins[4 * kHistReplicas][256];
+    img += (size_t)blockIdx.y * stride;
+    hist += (size_t)blockIdx.y * 256;
+    for (int i = threadIdx.x; i < 4 * kHistReplicas * 256; i += 256) (&bins[0][0])[i] = 0;
     __syncthreads();
-    const int wave = threadIdx.x >> 6;
-    const uint32_t p0 = blockIdx.x * px_per_block;
-    const uint32_t p1 = min(npix, p0 + px_per_block);
-    for (uint32_t p = p0 + threadIdx.x; p < p1; p += 256)
-        atomicAdd(&bins[wave][gray3[(size_t)p * 3]], 1);
+    int32_t *mine = bins[(threadIdx.x >> 6) * kHistReplicas + (threadIdx.x & (kHistReplicas - 1))];
+#pragma unroll 1
+    for (int it = 0; it < kHistBlocks; it++) {
+        const uint32_t lane_px = ((blockIdx.x * kHistBlocks + it) * 256u + threadIdx.x) * 16u;
+        if (lane_px >= npix) break;
+        const uint32_t rem = npix - lane_px;
+        const size_t off = (size_t)lane_px * 3;
+        if (FAST && rem >= 16) {
+            const Px16 p = load_px16<true>(img + off, 48);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t g = MODE == 0 ? get_byte(p, 3 * k)
+                                             : gray_of<MODE == 2>(get_byte(p, 3 * k), get_byte(p, 3 * k + 1),
+                                                                  get_byte(p, 3 * k + 2));
+                atomicAdd(&mine[g], 1);
+            }
+        } else {
+            const uint32_t cntpx = rem < 16 ? rem : 16;
+            for (uint32_t k = 0; k < cntpx; k++) {
+                const uint8_t *q = img + off + 3 * k;
+                const uint32_t g = MODE == 0 ? q[0] : gray_of<MODE == 2>(q[0], q[1], q[2]);
+                atomicAdd(&mine[g], 1);
+            }
+        }
+    }
     __syncthreads();
-    const int v = bins[0][threadIdx.x] + bins[1][threadIdx.x] + bins[2][threadIdx.x] +
-                  bins[3][threadIdx.x];
+    int v = 0;
+#pragma unroll
+    for (int r = 0; r < 4 * kHistReplicas; r++) v += bins[r][threadIdx.x];
     if (v) atomicAdd(&hist[threadIdx.x], v);
 }
 
-// server.cpp:108-127 executed as written by one lane (256 iterations; the dead `else if` included).
+// server.cpp:108-127 executed as written by one lane per frame (256 iterations; dead `else if` kept).
 __global__ void k_two_max_threshold(const int32_t *histogram, int32_t *thr_out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
+    histogram += (size_t)blockIdx.x * 256;
     int max = -1, sec_max = -1;
     int index_max = -1, index_sec_max = -1;
     for (int i = 0; i < 256; i++) {
@@ -181,13 +218,15 @@ __global__ void k_two_max_threshold(const int32_t *histogram, int32_t *thr_out) 
     int threshold = (index_max + index_sec_max) / 2;
     if (threshold < 50) threshold = 50;
     if (threshold > 200) threshold = 200;
-    *thr_out = threshold;
+    thr_out[blockIdx.x] = threshold;
 }
 
 // kernels.cu:222-241 / server.cpp:129-135: byte > thr ? 255 : 0, 16 bytes per lane.
 __global__ __launch_bounds__(256) void k_binarize(const uint8_t *in, uint8_t *out, uint32_t nbytes,
-                                                  const int32_t *thr_p, bool fast) {
-    const uint32_t thr = (uint32_t)*thr_p;
+                                                  const int32_t *thr_p, bool fast, size_t stride) {
+    in += (size_t)blockIdx.y * stride;
+    out += (size_t)blockIdx.y * stride;
+    const uint32_t thr = (uint32_t)thr_p[blockIdx.y];
     const uint32_t off = (blockIdx.x * 256u + threadIdx.x) * 16u;
     if (off >= nbytes) return;
     if (fast && off + 16 <= nbytes) {
@@ -208,21 +247,92 @@ __global__ __launch_bounds__(256) void k_binarize(const uint8_t *in, uint8_t *ou
     }
 }
 
-hipError_t launch_binarize_chain(const uint8_t *gray, uint8_t *out, uint32_t nbytes, int32_t *hist,
-                                 int32_t *thr, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(hist, 0, 256 * sizeof(int32_t), s);
-    if (e != hipSuccess) return e;
-    const uint32_t npix = nbytes / 3;
-    if (npix) {
-        const uint32_t px_per_block = 256 * 32;
-        hipLaunchKernelGGL(k_histogram, dim3((npix + px_per_block - 1) / px_per_block), dim3(256), 0, s,
-                           gray, npix, hist, px_per_block);
+// Fused second pass of config 3: colour in -> gray (avg or weighted) -> > thr -> 0/255 in the 3 channels.
+template <bool WEIGHTED, bool FAST>
+__global__ __launch_bounds__(256) void k_gray_binarize(const uint8_t *in, uint8_t *out, uint32_t npix,
+                                                       const int32_t *thr_p, size_t stride) {
+    in += (size_t)blockIdx.y * stride;
+    out += (size_t)blockIdx.y * stride;
+    const uint32_t thr = (uint32_t)thr_p[blockIdx.y];
+    const uint32_t lane_px = (blockIdx.x * 256u + threadIdx.x) * 16u;
+    if (lane_px >= npix) return;
+    const uint32_t rem = npix - lane_px;
+    const size_t off = (size_t)lane_px * 3;
+    if (FAST && rem >= 16) {
+        const Px16 p = load_px16<true>(in + off, 48);
+        Px16 q;
+#pragma unroll
+        for (int i = 0; i < 12; i++) q.w[i] = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t g =
+                gray_of<WEIGHTED>(get_byte(p, 3 * k), get_byte(p, 3 * k + 1), get_byte(p, 3 * k + 2));
+            const uint32_t v = g > thr ? 255u : 0u;
+            put_byte(q, 3 * k, v); put_byte(q, 3 * k + 1, v); put_byte(q, 3 * k + 2, v);
+        }
+        store_px16<true>(out + off, q, 48);
+    } else {
+        const uint32_t cntpx = rem < 16 ? rem : 16;
+        for (uint32_t k = 0; k < cntpx; k++) {
+            const uint8_t *p = in + off + 3 * k;
+            const uint8_t v = gray_of<WEIGHTED>(p[0], p[1], p[2]) > thr ? 255 : 0;
+            uint8_t *q = out + off + 3 * k;
+            q[0] = v; q[1] = v; q[2] = v;
+        }
     }
-    hipLaunchKernelGGL(k_two_max_threshold, dim3(1), dim3(64), 0, s, hist, thr);
+}
+
+static hipError_t launch_hist_thr(const uint8_t *img, uint32_t npix, int mode, int32_t *hist, int32_t *thr,
+                                  FrameBatch fb, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)fb.nframes * 256 * sizeof(int32_t), s);
+    if (e != hipSuccess) return e;
+    if (npix) {
+        const uint32_t px_per_block = 256 * 16 * kHistBlocks;
+        const dim3 g((npix + px_per_block - 1) / px_per_block, (unsigned)fb.nframes);
+        const bool fast = aligned16(img) && fb.stride % 16 == 0;
+#define MI355_HIST(M)                                                                                   \
+    do {                                                                                                \
+        if (fast) hipLaunchKernelGGL((k_histogram<M, true>), g, dim3(256), 0, s, img, npix, hist, fb.stride); \
+        else hipLaunchKernelGGL((k_histogram<M, false>), g, dim3(256), 0, s, img, npix, hist, fb.stride);     \
+    } while (0)
+        if (mode == 0) MI355_HIST(0);
+        else if (mode == 1) MI355_HIST(1);
+        else MI355_HIST(2);
+#undef MI355_HIST
+    }
+    hipLaunchKernelGGL(k_two_max_threshold, dim3(fb.nframes), dim3(64), 0, s, hist, thr);
+    return hipGetLastError();
+}
+
+hipError_t launch_binarize_chain(const uint8_t *gray, uint8_t *out, uint32_t nbytes, int32_t *hist,
+                                 int32_t *thr, FrameBatch fb, hipStream_t s) {
+    if (fb.nframes <= 0) return hipSuccess;
+    hipError_t e = launch_hist_thr(gray, nbytes / 3, 0, hist, thr, fb, s);
+    if (e != hipSuccess) return e;
     if (nbytes) {
         const uint32_t lanes = (nbytes + 15) / 16;
-        hipLaunchKernelGGL(k_binarize, dim3((lanes + 255) / 256), dim3(256), 0, s, gray, out, nbytes, thr,
-                           aligned16(gray) && aligned16(out));
+        hipLaunchKernelGGL(k_binarize, dim3((lanes + 255) / 256, (unsigned)fb.nframes), dim3(256), 0, s, gray,
+                           out, nbytes, thr, aligned16(gray) && aligned16(out) && fb.stride % 16 == 0, fb.stride);
+    }
+    return hipGetLastError();
+}
+
+// config 3 fused: colour -> (gray, histogram) ; threshold ; colour -> gray -> binarize.  2N read + N
+// write per frame instead of (N+N) + N/3 + (N+N) for the unfused chain.
+hipError_t launch_gray_binarize_fused(const uint8_t *color, uint8_t *out, uint32_t npix, bool weighted,
+                                      int32_t *hist, int32_t *thr, FrameBatch fb, hipStream_t s) {
+    if (fb.nframes <= 0) return hipSuccess;
+    hipError_t e = launch_hist_thr(color, npix, weighted ? 2 : 1, hist, thr, fb, s);
+    if (e != hipSuccess || npix == 0) return e;
+    const bool fast = aligned16(color) && aligned16(out) && fb.stride % 16 == 0;
+    dim3 g = px16_grid(npix);
+    g.y = (unsigned)fb.nframes;
+    if (weighted) {
+        if (fast) hipLaunchKernelGGL((k_gray_binarize<true, true>), g, dim3(256), 0, s, color, out, npix, thr, fb.stride);
+        else hipLaunchKernelGGL((k_gray_binarize<true, false>), g, dim3(256), 0, s, color, out, npix, thr, fb.stride);
+    } else {
+        if (fast) hipLaunchKernelGGL((k_gray_binarize<false, true>), g, dim3(256), 0, s, color, out, npix, thr, fb.stride);
+        else hipLaunchKernelGGL((k_gray_binarize<false, false>), g, dim3(256), 0, s, color, out, npix, thr, fb.stride);
     }
     return hipGetLastError();
 }
@@ -232,8 +342,11 @@ hipError_t launch_binarize_chain(const uint8_t *gray, uint8_t *out, uint32_t nby
 // exact double expression; staged in LDS.
 template <bool FAST>
 __global__ __launch_bounds__(256) void k_heat_map(const uint8_t *cur, const uint8_t *prev, uint8_t *out,
-                                                  uint32_t npix, const uint8_t *lut) {
+                                                  uint32_t npix, const uint8_t *lut, size_t stride) {
     __shared__ uint8_t s_lut[768 * 3];
+    cur += (size_t)blockIdx.y * stride;
+    prev += (size_t)blockIdx.y * stride;
+    out += (size_t)blockIdx.y * stride;
     for (int i = threadIdx.x; i < 766 * 3; i += 256) s_lut[i] = lut[i];
     __syncthreads();
     const uint32_t lane_px = (blockIdx.x * 256u + threadIdx.x) * 16u;
@@ -264,18 +377,23 @@ __global__ __launch_bounds__(256) void k_heat_map(const uint8_t *cur, const uint
 }
 
 hipError_t launch_heat_map(const uint8_t *cur, const uint8_t *prev, uint8_t *out, uint32_t npix,
-                           const uint8_t *lut, hipStream_t s) {
-    if (npix == 0) return hipSuccess;
-    const bool fast = aligned16(cur) && aligned16(prev) && aligned16(out);
-    if (fast) hipLaunchKernelGGL((k_heat_map<true>), px16_grid(npix), dim3(256), 0, s, cur, prev, out, npix, lut);
-    else hipLaunchKernelGGL((k_heat_map<false>), px16_grid(npix), dim3(256), 0, s, cur, prev, out, npix, lut);
+                           const uint8_t *lut, FrameBatch fb, hipStream_t s) {
+    if (npix == 0 || fb.nframes <= 0) return hipSuccess;
+    const bool fast = aligned16(cur) && aligned16(prev) && aligned16(out) && fb.stride % 16 == 0;
+    dim3 g = px16_grid(npix);
+    g.y = (unsigned)fb.nframes;
+    if (fast) hipLaunchKernelGGL((k_heat_map<true>), g, dim3(256), 0, s, cur, prev, out, npix, lut, fb.stride);
+    else hipLaunchKernelGGL((k_heat_map<false>), g, dim3(256), 0, s, cur, prev, out, npix, lut, fb.stride);
     return hipGetLastError();
 }
 
 // ---- red motion map, dense: tests/heat_map_red_benchmark/cpu.cu:38-55 (test.cu:142-168) -----------
 template <bool FAST>
 __global__ __launch_bounds__(256) void k_red_dense(const uint8_t *cur, const uint8_t *prev, uint8_t *out,
-                                                   uint32_t npix, int thr) {
+                                                   uint32_t npix, int thr, size_t stride) {
+    cur += (size_t)blockIdx.y * stride;
+    prev += (size_t)blockIdx.y * stride;
+    out += (size_t)blockIdx.y * stride;
     const uint32_t lane_px = (blockIdx.x * 256u + threadIdx.x) * 16u;
     if (lane_px >= npix) return;
     const uint32_t rem = npix - lane_px;
@@ -303,11 +421,13 @@ __global__ __launch_bounds__(256) void k_red_dense(const uint8_t *cur, const uin
 }
 
 hipError_t launch_red_dense(const uint8_t *cur, const uint8_t *prev, uint8_t *out, uint32_t npix,
-                            int thr, hipStream_t s) {
-    if (npix == 0) return hipSuccess;
-    const bool fast = aligned16(cur) && aligned16(prev) && aligned16(out);
-    if (fast) hipLaunchKernelGGL((k_red_dense<true>), px16_grid(npix), dim3(256), 0, s, cur, prev, out, npix, thr);
-    else hipLaunchKernelGGL((k_red_dense<false>), px16_grid(npix), dim3(256), 0, s, cur, prev, out, npix, thr);
+                            int thr, FrameBatch fb, hipStream_t s) {
+    if (npix == 0 || fb.nframes <= 0) return hipSuccess;
+    const bool fast = aligned16(cur) && aligned16(prev) && aligned16(out) && fb.stride % 16 == 0;
+    dim3 g = px16_grid(npix);
+    g.y = (unsigned)fb.nframes;
+    if (fast) hipLaunchKernelGGL((k_red_dense<true>), g, dim3(256), 0, s, cur, prev, out, npix, thr, fb.stride);
+    else hipLaunchKernelGGL((k_red_dense<false>), g, dim3(256), 0, s, cur, prev, out, npix, thr, fb.stride);
     return hipGetLastError();
 }
 
@@ -337,13 +457,83 @@ hipError_t launch_red_overlap(uint8_t *img, const int32_t *xs, const uint32_t *d
 // ---- 3x3 noise filter: kernels.cu:97-136 --------------------------------------------------------------
 // out[y][x][c] = (uint8) sum_{i,j} k[3i+j] * in[y+i-1][x+j-1][c], zero outside the image, float
 // accumulator, taps in i-major / j-minor order, one multiply then one add per tap.
-// A workgroup stages ROWS+2 input rows of a 3*TW-byte column band (+1 pixel halo each side) in LDS.
-constexpr int kConvTW = 64;    // output pixels per band
-constexpr int kConvRows = 8;   // output rows per workgroup
+// On the interleaved byte image this is a 2-D filter with a horizontal tap spacing of 3 bytes.
+//
+// k_conv3x3_rows (rows 16-byte aligned, i.e. 3*w % 16 == 0 -- 1080p and 4K): a workgroup produces
+// 4 rows x 1024 bytes; the 6 input rows x (1024 + 2*16) bytes are staged in LDS with 16-byte loads and
+// every lane computes 16 consecutive output bytes from three aligned 48-byte LDS windows per row
+// (66 byte->float conversions, 144 multiplies + 144 adds, 16 float->byte conversions: the kernel is
+// VALU-bound, not HBM-bound).  k_conv3x3_any is the byte-wise form for every other geometry.
+constexpr int kConvCols = 1024;   // output bytes per tile row (64 lanes x 16 B)
+constexpr int kConvRowsV = 4;     // output rows per workgroup
 
-__global__ __launch_bounds__(256) void k_conv3x3(const uint8_t *in, uint8_t *out, int w, int h,
-                                                 const float *k9) {
+__device__ __forceinline__ float byte_f(uint32_t dw, int b) {  // b is a compile-time constant
+    return (float)((dw >> (8 * b)) & 0xffu);                   // v_cvt_f32_ubyteN
+}
+
+__global__ __launch_bounds__(256) void k_conv3x3_rows(const uint8_t *in, uint8_t *out, int rowbytes, int h,
+                                                      const float *k9, size_t stride) {
+    __shared__ uint4 tile[kConvRowsV + 2][kConvCols / 16 + 2];
+    in += (size_t)blockIdx.z * stride;
+    out += (size_t)blockIdx.z * stride;
+    const int xb0 = blockIdx.x * kConvCols, y0 = blockIdx.y * kConvRowsV;
+    float kk[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) kk[i] = k9[i];
+    // stage: chunk (ry, cx) holds image bytes [xb0 - 16 + 16*cx, +16) of row y0 - 1 + ry
+    constexpr int kChunks = kConvCols / 16 + 2;
+    for (int i = threadIdx.x; i < (kConvRowsV + 2) * kChunks; i += 256) {
+        const int ry = i / kChunks, cx = i - ry * kChunks;
+        const int gy = y0 - 1 + ry, gx = xb0 - 16 + 16 * cx;
+        uint4 v = make_uint4(0, 0, 0, 0);                          // zero halo, kernels.cu:111-115
+        if (gy >= 0 && gy < h && gx >= 0 && gx < rowbytes)         // rowbytes % 16 == 0: whole chunks
+            v = *reinterpret_cast<const uint4 *>(in + (size_t)gy * rowbytes + gx);
+        tile[ry][cx] = v;
+    }
+    __syncthreads();
+    const int r = threadIdx.x >> 6, c = threadIdx.x & 63;
+    const int gy = y0 + r, gx = xb0 + 16 * c;
+    if (gy >= h || gx >= rowbytes) return;
+    float acc[16];
+#pragma unroll
+    for (int b = 0; b < 16; b++) acc[b] = 0.0f;                    // kernels.cu:120-122
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        // window = bytes [16c - 16, 16c + 32) of input row r + i (tile chunks c, c+1, c+2)
+        const uint4 a = tile[r + i][c], m = tile[r + i][c + 1], z = tile[r + i][c + 2];
+        // f[n] = byte (16c - 3 + n), n = 0..21
+        float f[22];
+        f[0] = byte_f(a.w, 1); f[1] = byte_f(a.w, 2); f[2] = byte_f(a.w, 3);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            f[3 + b] = byte_f(m.x, b); f[7 + b] = byte_f(m.y, b);
+            f[11 + b] = byte_f(m.z, b); f[15 + b] = byte_f(m.w, b);
+        }
+        f[19] = byte_f(z.x, 0); f[20] = byte_f(z.x, 1); f[21] = byte_f(z.x, 2);
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const float prod = kk[i * 3 + j] * f[b + 3 * j];   // kernels.cu:126-128: multiply ...
+                acc[b] = acc[b] + prod;                            // ... then add
+            }
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        o[q] = ((uint32_t)acc[4 * q] & 0xffu) | (((uint32_t)acc[4 * q + 1] & 0xffu) << 8) |
+               (((uint32_t)acc[4 * q + 2] & 0xffu) << 16) | ((uint32_t)acc[4 * q + 3] << 24);   // :131-133
+    *reinterpret_cast<uint4 *>(out + (size_t)gy * rowbytes + gx) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+constexpr int kConvTW = 64;    // output pixels per band (byte-wise kernel)
+constexpr int kConvRows = 8;   // output rows per workgroup (byte-wise kernel)
+
+__global__ __launch_bounds__(256) void k_conv3x3_any(const uint8_t *in, uint8_t *out, int w, int h,
+                                                     const float *k9, size_t stride) {
     __shared__ uint8_t tile[kConvRows + 2][(kConvTW + 2) * 3 + 2];
+    in += (size_t)blockIdx.z * stride;
+    out += (size_t)blockIdx.z * stride;
     __shared__ float sk[9];
     if (threadIdx.x < 9) sk[threadIdx.x] = k9[threadIdx.x];
     const int x0 = blockIdx.x * kConvTW, y0 = blockIdx.y * kConvRows;
@@ -374,10 +564,18 @@ __global__ __launch_bounds__(256) void k_conv3x3(const uint8_t *in, uint8_t *out
     }
 }
 
-hipError_t launch_conv3x3(const uint8_t *in, uint8_t *out, int w, int h, const float *k9, hipStream_t s) {
-    if (w <= 0 || h <= 0) return hipSuccess;
-    const dim3 grid((w + kConvTW - 1) / kConvTW, (h + kConvRows - 1) / kConvRows);
-    hipLaunchKernelGGL(k_conv3x3, grid, dim3(256), 0, s, in, out, w, h, k9);
+hipError_t launch_conv3x3(const uint8_t *in, uint8_t *out, int w, int h, const float *k9, FrameBatch fb,
+                          hipStream_t s) {
+    if (w <= 0 || h <= 0 || fb.nframes <= 0) return hipSuccess;
+    const int rowbytes = 3 * w;
+    if (rowbytes % 16 == 0 && aligned16(in) && aligned16(out) && fb.stride % 16 == 0) {
+        const dim3 grid((rowbytes + kConvCols - 1) / kConvCols, (h + kConvRowsV - 1) / kConvRowsV,
+                        (unsigned)fb.nframes);
+        hipLaunchKernelGGL(k_conv3x3_rows, grid, dim3(256), 0, s, in, out, rowbytes, h, k9, fb.stride);
+    } else {
+        const dim3 grid((w + kConvTW - 1) / kConvTW, (h + kConvRows - 1) / kConvRows, (unsigned)fb.nframes);
+        hipLaunchKernelGGL(k_conv3x3_any, grid, dim3(256), 0, s, in, out, w, h, k9, fb.stride);
+    }
     return hipGetLastError();
 }
 

@@ -43,19 +43,26 @@ hipError_t launch_scan(const uint4 *meta, uint32_t *segoff, uint32_t *totals, ui
                        int nframes, uint32_t *offsets, hipStream_t s);
 hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s);
 
-// filters.hip
+// filters.hip -- every per-frame kernel takes a FrameBatch: frame f lives at base + f*stride
+struct FrameBatch {
+    size_t stride;
+    int nframes;
+};
 hipError_t launch_int_diff(const int32_t *cur, const int32_t *prev, int32_t *out, size_t n,
                            hipStream_t s);
-hipError_t launch_gray(const uint8_t *in, uint8_t *out, uint32_t npix, bool weighted, hipStream_t s);
+hipError_t launch_gray(const uint8_t *in, uint8_t *out, uint32_t npix, bool weighted, FrameBatch fb,
+                       hipStream_t s);
 hipError_t launch_binarize_chain(const uint8_t *gray, uint8_t *out, uint32_t nbytes, int32_t *hist,
-                                 int32_t *thr, hipStream_t s);
+                                 int32_t *thr, FrameBatch fb, hipStream_t s);
+hipError_t launch_gray_binarize_fused(const uint8_t *color, uint8_t *out, uint32_t npix, bool weighted,
+                                      int32_t *hist, int32_t *thr, FrameBatch fb, hipStream_t s);
 hipError_t launch_heat_map(const uint8_t *cur, const uint8_t *prev, uint8_t *out, uint32_t npix,
-                           const uint8_t *lut, hipStream_t s);
+                           const uint8_t *lut, FrameBatch fb, hipStream_t s);
 hipError_t launch_red_dense(const uint8_t *cur, const uint8_t *prev, uint8_t *out, uint32_t npix,
-                            int thr, hipStream_t s);
+                            int thr, FrameBatch fb, hipStream_t s);
 hipError_t launch_red_overlap(uint8_t *img, const int32_t *xs, const uint32_t *d_count,
                               uint32_t count, uint32_t nbytes, hipStream_t s);
-hipError_t launch_conv3x3(const uint8_t *in, uint8_t *out, int w, int h, const float *k9,
+hipError_t launch_conv3x3(const uint8_t *in, uint8_t *out, int w, int h, const float *k9, FrameBatch fb,
                           hipStream_t s);
 hipError_t launch_blit_glyph(uint8_t *frame, const uint8_t *glyph, int glyph_h, int glyph_wbytes,
                              int x_off_bytes, int frame_wbytes, int frame_h, hipStream_t s);

@@ -17,6 +17,8 @@ ERR_HIP = -2
 ERR_STATE = -3
 
 VIS_NONE, VIS_HEAT, VIS_RED, VIS_RED_OVERLAP, VIS_GRAY, VIS_BINARIZE = range(6)
+(OP_GRAY_AVG, OP_GRAY_WEIGHTED, OP_BINARIZE, OP_GRAY_AVG_BINARIZE, OP_GRAY_WEIGHTED_BINARIZE, OP_HEAT_MAP,
+ OP_RED_DENSE, OP_CONV3X3) = range(1, 9)
 
 
 class Config(C.Structure):
@@ -40,6 +42,7 @@ SYMBOLS = {
     "mi355_frame_bytes": (C.c_size_t, [C.c_void_p]),
     "mi355_workspace_bytes": (C.c_size_t, [C.c_void_p]),
     "mi355_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi355_use_own_stream": (C.c_int, [C.c_void_p]),
     "mi355_synchronize": (C.c_int, [C.c_void_p]),
     "mi355_set_state": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi355_get_state": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -58,6 +61,7 @@ SYMBOLS = {
     "mi355_red_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi355_red_overlap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "mi355_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355_filter_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "mi355_exec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]),
     "mi355_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "mi355_host_free": (C.c_int, [C.c_void_p]),

@@ -63,9 +63,11 @@ size_t mi355_frame_bytes(const mi355_core *core);
 /* Bytes of HBM workspace held by the core (state, logs, counters). */
 size_t mi355_workspace_bytes(const mi355_core *core);
 
-/* Use an existing hipStream_t (e.g. PyTorch's current stream) instead of the core's own stream;
- * NULL restores the core's stream. */
+/* A core starts on a stream of its own.  mi355_set_stream makes it enqueue on an existing hipStream_t
+ * instead (e.g. PyTorch's current stream; NULL is the default stream), so that the caller's own work
+ * on that stream is ordered with the core's; mi355_use_own_stream goes back. */
 int mi355_set_stream(mi355_core *core, void *hip_stream);
+int mi355_use_own_stream(mi355_core *core);
 int mi355_synchronize(mi355_core *core);
 
 /* ---- state: the reconstructed client frame ("previous" with negative feedback) ------------------
@@ -124,6 +126,21 @@ int mi355_red_overlap(mi355_core *core, void *d_img, const void *d_xs, const voi
                       uint32_t count);
 /* kernels.cu:97-136: 3x3 convolution with the kernel of mi355_set_conv_kernel; not in-place. */
 int mi355_conv3x3(mi355_core *core, const void *d_in, void *d_out);
+
+/* Batched form of the per-frame filters: nframes frames at d_in + t*stride_bytes (and d_in2 + t*stride_bytes
+ * for the two-input filters) -> d_out + t*stride_bytes, one launch per kernel for the whole batch.
+ * The *_BINARIZE ops compute one histogram and one two-max threshold per frame; the fused forms read
+ * the colour frame twice and never materialise the gray frame (BASELINE config 3). */
+#define MI355_OP_GRAY_AVG 1                /* kernels.cu:31-43                         */
+#define MI355_OP_GRAY_WEIGHTED 2           /* kernels.cu:67-95                         */
+#define MI355_OP_BINARIZE 3                /* gray3 in: kernels.cu:138-241             */
+#define MI355_OP_GRAY_AVG_BINARIZE 4       /* colour in: server.cpp:96-135 in one call */
+#define MI355_OP_GRAY_WEIGHTED_BINARIZE 5  /* colour in: kernels.cu:493-498 (visualizer 5) */
+#define MI355_OP_HEAT_MAP 6                /* d_in = cur, d_in2 = prev: kernels.cu:243-270 */
+#define MI355_OP_RED_DENSE 7               /* d_in = cur, d_in2 = prev: test.cu:142-168 */
+#define MI355_OP_CONV3X3 8                 /* kernels.cu:97-136, not in place          */
+int mi355_filter_batch(mi355_core *core, int op, const void *d_in, const void *d_in2, void *d_out,
+                       size_t stride_bytes, int nframes);
 
 /* ---- the per-frame host entry point: CUDACore::exec_core (kernels.cu:430-525) -------------------
  * frame_data: in = the captured frame (N bytes), out = diff[0..*h_pos)      (kernels.cu:461,522)

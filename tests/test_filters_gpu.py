@@ -220,3 +220,84 @@ def test_exec_core_1080p(po):
             pos = core.exec_core(h_frame.array, None, "", h_xs.array)
             c, xs, df, state = po.diff_pack(frames[t], state)
             assert pos == c and np.array_equal(h_xs.array[:pos], xs) and np.array_equal(h_frame.array[:pos], df)
+
+
+# ---- batched filters (one launch per kernel for T frames) ------------------------------------------
+
+@pytest.mark.parametrize("w,h,T", [(64, 48, 5), (37, 11, 3), (640, 360, 4)])
+def test_filter_batch_matches_per_frame_oracle(po, w, h, T):
+    n = 3 * w * h
+    base, frames = synth.webcam_stream(T + 1, w, h, seed=50)
+    cur, prev = frames[1:], frames[:-1]
+    k = po.gaussian_kernel(3, 1.5)
+    stride = n + (16 - n % 16) % 16 + 16          # padded, 16-byte aligned stride
+    def pad(a):
+        buf = np.zeros((a.shape[0], stride), np.uint8)
+        buf[:, :n] = a
+        return to_dev(buf)
+    d_cur, d_prev = pad(cur), pad(prev)
+    with CUDACore(w, h, k=k, max_batch=T) as core:
+        def run(op, second=None):
+            d_o = torch.full((T, stride), 0x5A, dtype=torch.uint8, device=DEV)
+            core.filter_batch(op, d_cur, d_o, T, d_in2=second, stride=stride)
+            core.synchronize()
+            return d_o.cpu().numpy()[:, :n]
+        exp = {
+            lib.OP_GRAY_AVG: [po.gray_avg(f) for f in cur],
+            lib.OP_GRAY_WEIGHTED: [po.gray_weighted(f) for f in cur],
+            lib.OP_GRAY_AVG_BINARIZE: [po.server_cpu_branch(f)[0] for f in cur],
+            lib.OP_GRAY_WEIGHTED_BINARIZE: [po.binarize(po.gray_weighted(f), po.two_max_threshold(po.histogram(po.gray_weighted(f)))) for f in cur],
+            lib.OP_CONV3X3: [po.conv3x3(f, w, h, k) for f in cur],
+        }
+        for op, e in exp.items():
+            got = run(op)
+            for t in range(T):
+                assert np.array_equal(got[t], e[t]), (op, t)
+        got = run(lib.OP_HEAT_MAP, d_prev)
+        for t in range(T):
+            assert np.array_equal(got[t], po.heat_map(cur[t], prev[t]))
+        got = run(lib.OP_RED_DENSE, d_prev)
+        for t in range(T):
+            assert np.array_equal(got[t], po.red_dense(cur[t], prev[t]))
+        # gray3 -> binarize (unfused form) on the batch
+        d_gray = torch.zeros((T, stride), dtype=torch.uint8, device=DEV)
+        core.filter_batch(lib.OP_GRAY_AVG, d_cur, d_gray, T, stride=stride)
+        d_o = torch.zeros((T, stride), dtype=torch.uint8, device=DEV)
+        core.filter_batch(lib.OP_BINARIZE, d_gray, d_o, T, stride=stride)
+        core.synchronize()
+        for t in range(T):
+            assert np.array_equal(d_o[t, :n].cpu().numpy(), po.server_cpu_branch(cur[t])[0])
+
+
+def test_fused_binarize_vs_reference_fixture():
+    """config 3 fused chain (avg form) == the reference's own server.cpp CPU branch outputs."""
+    g = golden("ref_server_cpu_64x48.npz")
+    w, h = int(g["width"]), int(g["height"])
+    T = g["frames"].shape[0]
+    with CUDACore(w, h, max_batch=T) as core:
+        d_o = torch.zeros_like(to_dev(g["frames"]))
+        core.filter_batch(lib.OP_GRAY_AVG_BINARIZE, to_dev(g["frames"]), d_o, T)
+        core.synchronize()
+        assert np.array_equal(d_o.cpu().numpy(), g["out"])
+
+
+def test_config3_and_config4_at_1080p(po):
+    """BASELINE configs 3 and 4 at full size through exec_core: weighted gray + binarize visualiser,
+    and 3x3 noise filter + red motion map, each followed by the diff/threshold/pack."""
+    w, h = 1920, 1080
+    n = 3 * w * h
+    base, frames = synth.webcam_stream(2, w, h, seed=60, device=DEV)
+    base, frames = base.cpu().numpy(), frames.cpu().numpy()
+    k = po.gaussian_kernel(3, 1.5)
+    for vis, nf in ((lib.VIS_BINARIZE, False), (lib.VIS_RED, True)):
+        with CUDACore(w, h, k=k, sample_mat_data=base, visualizer=vis, noise_filter=nf) as core:
+            h_frame, n_frame, o_frame, h_xs = CUDACore.alloc_arrays(h, w)
+            state = base
+            for t in range(2):
+                h_frame.array[:n] = frames[t]
+                pos = core.exec_core(h_frame.array, n_frame.array, "", h_xs.array)
+                c, xs, df, state, show = oracle_exec(po, frames[t], state, vis, k, nf, w, h)
+                assert pos == c and np.array_equal(h_xs.array[:pos], xs) and np.array_equal(h_frame.array[:pos], df)
+                assert np.array_equal(n_frame.array[:n], show)
+            for a in (h_frame, n_frame, o_frame, h_xs):
+                a.free()

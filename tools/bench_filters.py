@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Secondary benchmark: the filter kernels (K2..K5) on batches of 1080p frames resident in HBM.
+
+Prints one JSON line per filter: microseconds per frame, algorithmic bytes per frame (DESIGN.md
+section 4) and the achieved GB/s against the 8 TB/s HBM peak.  Not the headline metric (bench.py)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cudavideostream_amd import CUDACore, lib, synth  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402  (only for the Gaussian kernel values)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--batch", type=int, default=96)
+    ap.add_argument("--reps", type=int, default=20)
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    W, H, B = a.width, a.height, a.batch
+    n = 3 * W * H
+    _, frames = synth.webcam_stream(B + 1, W, H, device=dev)
+    cur, prev = frames[1:], frames[:-1]
+    out = torch.empty((B, n), dtype=torch.uint8, device=dev)
+    core = CUDACore(W, H, k=po.gaussian_kernel(3, 1.5), max_batch=B)
+    core.use_torch_stream()
+    N = float(n)
+    ops = [
+        ("gray_avg", lib.OP_GRAY_AVG, None, 2 * N),
+        ("gray_weighted", lib.OP_GRAY_WEIGHTED, None, 2 * N),
+        ("binarize (gray3 in)", lib.OP_BINARIZE, None, N / 3 + 2 * N),
+        ("gray_weighted+binarize fused (config 3)", lib.OP_GRAY_WEIGHTED_BINARIZE, None, 3 * N),
+        ("heat_map", lib.OP_HEAT_MAP, prev, 3 * N),
+        ("red_dense", lib.OP_RED_DENSE, prev, 3 * N),
+        ("conv3x3", lib.OP_CONV3X3, None, 2 * N),
+    ]
+    for name, op, second, alg in ops:
+        for _ in range(3):
+            core.filter_batch(op, cur, out, B, d_in2=second)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(a.reps):
+            core.filter_batch(op, cur, out, B, d_in2=second)
+        ev1.record()
+        torch.cuda.synchronize()
+        us = ev0.elapsed_time(ev1) * 1e3 / (a.reps * B)
+        gbps = alg / (us * 1e-6) / 1e9
+        print(json.dumps({"filter": name, "us_per_frame": round(us, 3), "frames_per_s": round(1e6 / us, 1),
+                          "algorithmic_bytes_per_frame": int(alg), "achieved_gbps": round(gbps, 1),
+                          "frac_of_8TBps": round(gbps / 8000.0, 4), "batch": B}), flush=True)
+    core.close()
+
+
+if __name__ == "__main__":
+    main()
