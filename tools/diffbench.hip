@@ -51,7 +51,7 @@ __global__ void k_webcam_frame(uint8_t *out, int t, int width, int height, uint3
 }
 
 int main(int argc, char **argv) {
-    int W = 1920, H = 1080, B = 256, K = 20, WU = 3, checksum_t = -2;
+    int W = 1920, H = 1080, B = 256, K = 20, WU = 3, checksum_t = -2, ncores = 1;
     uint32_t seed = 21;
     bool pairs = false;
     for (int i = 1; i < argc; i++) {
@@ -64,6 +64,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--seed")) { int s = 21; next(s); seed = (uint32_t)s; }
         else if (!strcmp(argv[i], "--checksum")) next(checksum_t);
         else if (!strcmp(argv[i], "--pairs")) pairs = true;
+        else if (!strcmp(argv[i], "--cores")) next(ncores);
     }
     const size_t n = (size_t)3 * W * H;
     if (checksum_t >= -1) {  // print a checksum of one generated frame (generator cross-check)
@@ -79,6 +80,43 @@ int main(int argc, char **argv) {
 
     mi355_config cfg{};
     cfg.width = W; cfg.height = H; cfg.threshold = 20; cfg.max_batch = B; cfg.device = -1;
+    if (ncores > 1) {   // several independent streams, one core (own HIP stream) each, submitted round-robin
+        std::vector<mi355_core *> cores(ncores);
+        std::vector<uint8_t *> fr(ncores);
+        std::vector<uint32_t *> off(ncores);
+        std::vector<int32_t *> xs(ncores);
+        std::vector<uint8_t *> df(ncores);
+        const size_t cap = (size_t)B * n / 8 > (1u << 20) ? (size_t)B * n / 8 : (1u << 20);
+        const dim3 g((unsigned)((n + 255) / 256)), b(256);
+        std::vector<uint8_t> h_base(n);
+        for (int c = 0; c < ncores; c++) {
+            MI_OK(mi355_create(&cfg, &cores[c]));
+            HIP_OK(hipMalloc((void **)&fr[c], n * (size_t)(B + 1)));
+            for (int t = -1; t < B; t++)
+                hipLaunchKernelGGL(k_webcam_frame, g, b, 0, 0, fr[c] + (size_t)(t + 1) * n, t, W, H, seed + c);
+            HIP_OK(hipDeviceSynchronize());
+            HIP_OK(hipMemcpy(h_base.data(), fr[c], n, hipMemcpyDeviceToHost));
+            MI_OK(mi355_set_state(cores[c], h_base.data()));
+            HIP_OK(hipMalloc((void **)&off[c], sizeof(uint32_t) * (B + 1)));
+            HIP_OK(hipMalloc((void **)&xs[c], sizeof(int32_t) * cap));
+            HIP_OK(hipMalloc((void **)&df[c], cap));
+        }
+        auto round = [&]() {
+            for (int c = 0; c < ncores; c++)
+                MI_OK(mi355_diff_stream_batch(cores[c], fr[c] + n, n, B, off[c], xs[c], df[c], cap));
+        };
+        for (int i = 0; i < WU; i++) round();
+        for (int c = 0; c < ncores; c++) MI_OK(mi355_synchronize(cores[c]));
+        const auto t0 = std::chrono::high_resolution_clock::now();
+        for (int i = 0; i < K; i++) round();
+        for (int c = 0; c < ncores; c++) MI_OK(mi355_synchronize(cores[c]));
+        const double sec = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+        printf("{\"harness\": \"diffbench\", \"mode\": \"stream\", \"cores\": %d, \"batch\": %d, \"steps\": %d, "
+               "\"frames_per_s\": %.1f, \"ms_per_round\": %.4f}\n",
+               ncores, B, K, (double)ncores * B * K / sec, sec / K * 1e3);
+        for (auto c : cores) mi355_destroy(c);
+        return 0;
+    }
     mi355_core *core = nullptr;
     MI_OK(mi355_create(&cfg, &core));
 
