@@ -115,7 +115,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run (also at N = 1)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
     if args.gpus != world and rank == 0:
@@ -182,7 +182,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "1920x1080 RGB24 frames/sec (diff+threshold+pack); achieved HBM GB/s vs peak",
+            "metric": f"{W}x{H} RGB24 frames/sec (diff+threshold+pack); achieved HBM GB/s vs peak",
             "value": round(world * B * K / elapsed, 1),
             "unit": "frames/s",
             "n_gpus": world,

@@ -237,3 +237,26 @@ def test_4k_pair_vs_oracle(po):
         off, xs, df, _ = run_stream(core, cur, pair_prev=prev)
         eo, exs, edf = oracle_pairs(po, cur.cpu().numpy(), prev.cpu().numpy())
         assert np.array_equal(off, eo) and np.array_equal(xs, exs) and np.array_equal(df, edf)
+
+
+def test_4k_stream_vs_oracle(po):
+    """config 5 frame size as a stateful stream (3840x2160, 4 frames)."""
+    W, H, T = 3840, 2160, 4
+    base, frames = synth.webcam_stream(T, W, H, seed=31, device=DEV)
+    with CUDACore(W, H, max_batch=T) as core:
+        core.set_state(base.cpu().numpy())
+        off, xs, df, _ = run_stream(core, frames, capacity=T * 3 * W * H // 4)
+        eo, exs, edf, est = po.diff_stream(frames.cpu().numpy(), base.cpu().numpy())
+        assert np.array_equal(off, eo) and np.array_equal(xs, exs) and np.array_equal(df, edf)
+        assert np.array_equal(core.get_state(), est)
+
+
+def test_long_batch_crosses_expand_table_blocks(po):
+    """More than 256 frames in one batch: k_expand's per-tile table is rebuilt per 256-frame block and
+    the frame cut by a chunk boundary carries across blocks."""
+    w, h, T = 64, 36, 600
+    base, frames = synth.webcam_stream(T, w, h, seed=13)
+    frames = frames.copy()
+    frames[255:258] = frames[0]      # quiet frames around the first block boundary
+    with CUDACore(w, h, max_batch=T) as core:
+        check_stream(po, core, base, frames)
