@@ -107,6 +107,11 @@ def cpu_baseline(args, base, frames, dev):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the JSON record): anything libraries print while the job runs
+    # (RCCL prints a version banner on stdout at communicator creation) is routed to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -216,7 +221,10 @@ def main():
             out["cpu_baseline"], out["parity"] = cpu_baseline(args, base, frames, dev)
         else:
             out["cpu_baseline"] = None
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     core.close()
     if dist:
         dist.barrier()
