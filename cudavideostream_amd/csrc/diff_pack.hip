@@ -25,8 +25,8 @@
 //                 cache lines; all tiles' current chunks are neighbours in memory).  Per (frame, tile)
 //                 one 16-byte meta word keeps {candidate ballot, flagged-byte count, log position}.
 //   k_scan_*    : per frame exclusive scan of the byte counts over tiles, then scan of the frame totals.
-//   k_expand    : one wave per tile again, streaming the tile's log: turns records into the caller's
-//                 packed, frame-major, ascending (xs, diff) arrays.
+//   k_expand    : one workgroup per (frame, 64 tiles): turns records into the caller's packed,
+//                 frame-major, ascending (xs, diff) arrays through an LDS stage and coalesced stores.
 // No inter-workgroup communication inside a launch, no spin waits, results independent of dispatch
 // order.
 #include "internal.h"
@@ -384,14 +384,14 @@ hipError_t launch_scan(const uint4 *meta, uint32_t *segoff, uint32_t *totals, ui
 }
 
 // ---- expand: records -> packed frame-major (xs, diff) -------------------------------------------------
-// grid = ceil(W/4), block = 256: like k_diff_pack, one wave owns one tile -- here it streams the tile's
-// record log, 64 consecutive records (one 1 KiB chunk, fully coalesced) per step with the next chunk
-// already in flight.  No workgroup barriers and no dependent global loads inside the loop: the
-// per-frame facts of the tile (log position, candidate ballot, output base = offsets[t] +
-// segoff[t][tile]) are staged once per 256 frames in a wave-private LDS table.  For its record the
-// lane finds the frame (binary search of the log position), the source lane (k-th set bit of the
-// ballot) and its slot inside the (frame, tile) segment (segmented scan of the byte counts, with a
-// carry for the frame that straddles two chunks), then writes its <= 16 entries.
+// grid = (ceil(W/64), T), block = 256.  A workgroup owns 64 consecutive tiles of ONE frame: its output
+// is one contiguous range of the frame's segment, so the entries are staged in LDS in output order
+// and leave with fully coalesced stores (a dozen store instructions per workgroup instead of two
+// scattered ones per flagged byte).  A record is found from its index in the workgroup: tile by a
+// 6-step search of the record prefix, source lane as the k-th set bit of the tile's candidate ballot.
+// A pass covers up to 8 x 256 records; all record loads of a pass are issued before any is used and
+// the byte counts of two rounds share a register, so a pass costs 4 DPP scans and two barriers.
+// 1080p webcam-like input: ~1200 records and ~1500 entries per workgroup, one pass.
 __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t v) {   // 0x80 per nonzero byte
     return (((v & kL) + kL) | v) & kH;
 }
@@ -410,146 +410,138 @@ __device__ __forceinline__ int kth_set_bit(uint64_t mask, uint32_t k) {
     return base;
 }
 
-constexpr int kExpandFrames = 256;   // frames per LDS table block
-constexpr int kExpandGroup = 4;      // chunks per register group (two groups: 8 KiB in flight per wave)
+#ifndef MI355_XTILES
+#define MI355_XTILES 64
+#endif
+constexpr uint32_t kXTiles = MI355_XTILES;   // tiles per workgroup (power of two, <= 64)
+constexpr int kXLog = kXTiles == 64 ? 6 : kXTiles == 32 ? 5 : kXTiles == 16 ? 4 : 3;
+#ifndef MI355_XROUNDS
+#define MI355_XROUNDS 4
+#endif
+constexpr int kXRounds = MI355_XROUNDS;   // rounds of 256 records per pass (even)
+constexpr uint32_t kXEntries = 3072;    // entries staged in LDS per workgroup; denser workgroups store directly
 
-struct ExpandWave {      // per-wave state of k_expand
-    const uint32_t *recpos;   // LDS: log position of frame f (+ end sentinel)
-    const uint32_t *obase;    // LDS: output index of the (frame, tile) segment
-    const uint64_t *cmask;    // LDS: candidate ballot of frame f
-    uint32_t tile, nb, tb, p_begin, p_end;
-    uint32_t fcur;            // frame containing the first position of the current chunk
-    uint32_t last_t, last_bytes;   // frame cut by the previous chunk boundary and its bytes so far
-};
-
-// Loads are always issued (position clamped into the block's range): as in k_diff_pack the number
-// of vector-memory operations younger than a load must be a compile-time constant, or the compiler
-// degrades every wait to vmcnt(0).
-__device__ __forceinline__ uint4 expand_load(const ExpandArgs &a, const ExpandWave &w, uint32_t c,
-                                             int lane) {
-    uint32_t p = (c << 6) + (uint32_t)lane;
-    p = max(min(p, w.p_end - 1u), w.p_begin);
-    return a.rec[rec_index(p, w.tile, a.ntiles)];
-}
-
-__device__ __forceinline__ void expand_chunk(const ExpandArgs &a, ExpandWave &w, uint32_t c,
-                                             const uint4 rec, int lane) {
-    const uint32_t c0 = c << 6, p = c0 + (uint32_t)lane;
-    const bool act = p >= w.p_begin && p < w.p_end;
-    // frame of this record: the largest f with recpos[f] <= p.  A chunk overlaps only a few frames
-    // (a 1080p webcam tile appends ~19 records per frame), so every lane walks forward from the
-    // chunk's first frame; the walk is bounded by the table size.
-    uint32_t f = w.fcur;
-    if (act) {
-        while (f + 1u < w.nb && w.recpos[f + 1u] <= p) ++f;
-    }
-    const uint32_t last_lane = min(w.p_end, c0 + 64u) - c0 - 1u;   // last active lane
-    w.fcur = (uint32_t)__builtin_amdgcn_readlane((int)f, (int)last_lane);
-    const uint32_t fpos = w.recpos[f];
-    const int src_lane = act ? kth_set_bit(w.cmask[f], p - fpos) : 0;
-    // 16-bit map of the record's nonzero (= flagged) bytes: v_dot4 gathers the four 0x80 marks of a
-    // dword into 4 adjacent bits
-    uint32_t m16 = 0;
-    if (act) {
-        const uint32_t g0 = __builtin_amdgcn_udot4(nonzero_bytes(rec.x), 0x08040201u, 0u, false);
-        const uint32_t g1 = __builtin_amdgcn_udot4(nonzero_bytes(rec.y), 0x08040201u, 0u, false);
-        const uint32_t g2 = __builtin_amdgcn_udot4(nonzero_bytes(rec.z), 0x08040201u, 0u, false);
-        const uint32_t g3 = __builtin_amdgcn_udot4(nonzero_bytes(rec.w), 0x08040201u, 0u, false);
-        m16 = (g0 + (g1 << 4) + (g2 << 8) + (g3 << 12)) >> 7;
-    }
-    const uint32_t cnt = (uint32_t)__builtin_popcount(m16);
-    // segmented exclusive scan: bytes of earlier records of the same frame
-    const uint32_t incl = (uint32_t)wave_inclusive_scan((int)cnt);
-    const uint32_t seg_first = fpos > c0 ? fpos - c0 : 0u;   // lane where frame f starts
-    const uint32_t before = (uint32_t)__builtin_amdgcn_ds_bpermute(
-        (int)((seg_first ? seg_first - 1u : 0u) << 2), (int)incl);
-    uint32_t within = incl - cnt - (seg_first ? before : 0u);
-    const uint32_t tg = w.tb + f;
-    if (seg_first == 0 && tg == w.last_t) within += w.last_bytes;
-    // the frame cut by the end of this chunk carries its byte count into the next chunk
-    w.last_t = (uint32_t)__builtin_amdgcn_readlane((int)tg, (int)last_lane);
-    w.last_bytes = (uint32_t)__builtin_amdgcn_readlane((int)(within + cnt), (int)last_lane);
-
-    if (m16) {
-        uint32_t o = w.obase[f] + within;   // < 2^32: the batch total is below 2^32
-        const uint32_t byte_base = w.tile * kTileBytes + (uint32_t)src_lane * 16u;
-        do {
-            const int j = __builtin_ctz(m16);
-            m16 &= m16 - 1;
-            const uint32_t dw = j < 8 ? (j < 4 ? rec.x : rec.y) : (j < 12 ? rec.z : rec.w);
-            if (o < a.capacity) {
-                a.out_xs[o] = (int32_t)(byte_base + (uint32_t)j);          // kernels.cu:315
-                a.out_diff[o] = (uint8_t)(dw >> (8 * (j & 3)));            // kernels.cu:314
-            }
-            ++o;
-        } while (m16);
-    }
-}
-
-__device__ __forceinline__ void expand_group(const ExpandArgs &a, ExpandWave &w, uint32_t c,
-                                             const uint4 (&g)[kExpandGroup], int lane) {
-#pragma unroll
-    for (int d = 0; d < kExpandGroup; d++)
-        if (((c + (uint32_t)d) << 6) < w.p_end) expand_chunk(a, w, c + (uint32_t)d, g[d], lane);
-}
-
-__global__ __launch_bounds__(256) void k_expand(const ExpandArgs a, int nframes) {
-    __shared__ uint32_t s_recpos[kWavesPerBlock][kExpandFrames + 1];
-    __shared__ uint32_t s_base[kWavesPerBlock][kExpandFrames];
-    __shared__ uint64_t s_mask[kWavesPerBlock][kExpandFrames];
+__global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
+    __shared__ uint64_t s_mask[kXTiles];
+    __shared__ uint32_t s_rincl[kXTiles];                 // inclusive prefix of records per tile
+    __shared__ uint32_t s_rpos[kXTiles];                  // log position of the tile's first record
+    __shared__ uint32_t s_wave[4][kXRounds / 2];          // per wave: packed byte totals per round pair
+    __shared__ uint32_t s_total;                          // entries of this workgroup
+    __shared__ int32_t s_xs[kXEntries];
+    __shared__ uint8_t s_df[kXEntries];
+    const int t = blockIdx.y;
+    const uint32_t tile0 = blockIdx.x * kXTiles;
+    const size_t row = (size_t)t * a.ntiles;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t tile = blockIdx.x * kWavesPerBlock + wave;
-    if (tile >= a.ntiles) return;  // wave-uniform; the kernel has no workgroup barrier
-    uint32_t *recpos = s_recpos[wave];
-    uint32_t *obase = s_base[wave];
-    uint64_t *cmask = s_mask[wave];
 
-    ExpandWave w;
-    w.recpos = recpos; w.obase = obase; w.cmask = cmask;
-    w.tile = tile;
-    w.last_t = 0xffffffffu; w.last_bytes = 0;
-    for (int tb = 0; tb < nframes; tb += kExpandFrames) {
-        const int nb = min(kExpandFrames, nframes - tb);
-        __builtin_amdgcn_wave_barrier();
-        for (int f = lane; f < nb; f += 64) {
-            const size_t idx = (size_t)(tb + f) * a.ntiles + tile;
-            const uint4 m = a.meta[idx];
-            const uint64_t mk = (uint64_t)m.x | ((uint64_t)m.y << 32);
-            recpos[f] = m.w;
-            cmask[f] = mk;
-            obase[f] = a.offsets[tb + f] + a.segoff[idx];
-            if (f == nb - 1) recpos[nb] = m.w + (uint32_t)__builtin_popcountll(mk);
+    if (wave == 0) {   // all 64 lanes take part in the DPP scans; lanes >= kXTiles carry zeros
+        const uint32_t tile = tile0 + (uint32_t)lane;
+        uint4 m = make_uint4(0, 0, 0, 0);
+        if ((uint32_t)lane < kXTiles && tile < a.ntiles) m = a.meta[row + tile];
+        const uint64_t mask = (uint64_t)m.x | ((uint64_t)m.y << 32);
+        const uint32_t rincl = (uint32_t)wave_inclusive_scan(__builtin_popcountll(mask));
+        const uint32_t bytes = (uint32_t)wave_inclusive_scan((int)m.z);
+        if ((uint32_t)lane < kXTiles) {
+            s_mask[lane] = mask;
+            s_rpos[lane] = m.w;
+            s_rincl[lane] = rincl;
         }
-        __builtin_amdgcn_wave_barrier();
-        w.nb = (uint32_t)nb; w.tb = (uint32_t)tb;
-        w.p_begin = recpos[0]; w.p_end = recpos[nb];
-        w.fcur = 0;
-        if (w.p_begin == w.p_end) continue;  // wave-uniform
+        if (lane == 63) s_total = bytes;
+    }
+    __syncthreads();
+    const uint32_t nrec = s_rincl[kXTiles - 1];
+    if (nrec == 0) return;
+    const uint32_t total = s_total;
+    const bool staged = total <= kXEntries;
+    const uint32_t dst0 = a.offsets[t] + a.segoff[row + tile0];   // < 2^32: the batch total is below 2^32
 
-        // two register groups of kExpandGroup chunks, as in k_diff_pack: the next group's loads are
-        // issued right before the wait for the current one
-        uint4 ga[kExpandGroup], gb[kExpandGroup];
-        uint32_t c = w.p_begin >> 6;
+    uint32_t carry = 0;   // entries of earlier passes
+    for (uint32_t base = 0; base < nrec; base += 256 * kXRounds) {
+        uint4 rec[kXRounds];
+        uint32_t byte_base[kXRounds];
 #pragma unroll
-        for (int d = 0; d < kExpandGroup; d++) ga[d] = expand_load(a, w, c + (uint32_t)d, lane);
-        for (;;) {
+        for (int j = 0; j < kXRounds; j++) {
+            rec[j] = make_uint4(0, 0, 0, 0);
+            byte_base[j] = 0;
+            const uint32_t r = base + (uint32_t)j * 256u + threadIdx.x;   // round j: contiguous records
+            if (r < nrec) {
+                uint32_t lo = 0, hi = kXTiles - 1;   // smallest sgm with s_rincl[sgm] > r
 #pragma unroll
-            for (int d = 0; d < kExpandGroup; d++) gb[d] = expand_load(a, w, c + kExpandGroup + (uint32_t)d, lane);
-            expand_group(a, w, c, ga, lane);
-            c += kExpandGroup;
-            if ((c << 6) >= w.p_end) break;
+                for (int it = 0; it < kXLog; it++) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_rincl[mid] > r) hi = mid; else lo = mid + 1;
+                }
+                const uint32_t sgm = lo;
+                const uint32_t k = r - (sgm ? s_rincl[sgm - 1] : 0u);
+                const int src_lane = kth_set_bit(s_mask[sgm], k);
+                byte_base[j] = (tile0 + sgm) * kTileBytes + (uint32_t)src_lane * 16u;
+                rec[j] = a.rec[rec_index(s_rpos[sgm] + k, tile0 + sgm, a.ntiles)];
+            }
+        }
+        // 16-bit maps of the nonzero (= flagged) bytes: v_dot4 gathers the four 0x80 marks of a dword
+        // into 4 adjacent bits
+        uint32_t m16[kXRounds], cnt[kXRounds], incl[kXRounds / 2];
 #pragma unroll
-            for (int d = 0; d < kExpandGroup; d++) ga[d] = expand_load(a, w, c + kExpandGroup + (uint32_t)d, lane);
-            expand_group(a, w, c, gb, lane);
-            c += kExpandGroup;
-            if ((c << 6) >= w.p_end) break;
+        for (int j = 0; j < kXRounds; j++) {
+            const uint32_t g0 = __builtin_amdgcn_udot4(nonzero_bytes(rec[j].x), 0x08040201u, 0u, false);
+            const uint32_t g1 = __builtin_amdgcn_udot4(nonzero_bytes(rec[j].y), 0x08040201u, 0u, false);
+            const uint32_t g2 = __builtin_amdgcn_udot4(nonzero_bytes(rec[j].z), 0x08040201u, 0u, false);
+            const uint32_t g3 = __builtin_amdgcn_udot4(nonzero_bytes(rec[j].w), 0x08040201u, 0u, false);
+            m16[j] = (g0 + (g1 << 4) + (g2 << 8) + (g3 << 12)) >> 7;
+            cnt[j] = (uint32_t)__builtin_popcount(m16[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < kXRounds / 2; j++) {      // a round total is at most 256*16 = 4096
+            incl[j] = (uint32_t)wave_inclusive_scan((int)(cnt[2 * j] | (cnt[2 * j + 1] << 16)));
+            if (lane == 63) s_wave[wave][j] = incl[j];
+        }
+        __syncthreads();
+        uint32_t run = carry;   // entries before round j (all waves), then before this wave in round j
+#pragma unroll
+        for (int j = 0; j < kXRounds; j++) {
+            const int sh = (j & 1) * 16;
+            uint32_t before = 0, round_total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const uint32_t v = (s_wave[w][j / 2] >> sh) & 0xffffu;
+                if (w < wave) before += v;
+                round_total += v;
+            }
+            uint32_t e = run + before + ((incl[j / 2] >> sh) & 0xffffu) - cnt[j];   // index in the workgroup
+            run += round_total;
+            uint32_t m = m16[j];
+            while (m) {
+                const int b = __builtin_ctz(m);
+                m &= m - 1;
+                const uint32_t dw = b < 8 ? (b < 4 ? rec[j].x : rec[j].y) : (b < 12 ? rec[j].z : rec[j].w);
+                const int32_t xs = (int32_t)(byte_base[j] + (uint32_t)b);          // kernels.cu:315
+                const uint8_t df = (uint8_t)(dw >> (8 * (b & 3)));                  // kernels.cu:314
+                if (staged) {
+                    s_xs[e] = xs;
+                    s_df[e] = df;
+                } else if ((size_t)dst0 + e < a.capacity) {
+                    a.out_xs[dst0 + e] = xs;
+                    a.out_diff[dst0 + e] = df;
+                }
+                ++e;
+            }
+        }
+        carry = run;
+        __syncthreads();   // s_wave is reused by the next pass; staged entries are complete after the last
+    }
+    if (staged) {
+        for (uint32_t e = threadIdx.x; e < total; e += 256) {
+            if ((size_t)dst0 + e < a.capacity) {
+                a.out_xs[dst0 + e] = s_xs[e];
+                a.out_diff[dst0 + e] = s_df[e];
+            }
         }
     }
 }
 
 hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s) {
-    const dim3 grid((a.ntiles + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL(k_expand, grid, dim3(64 * kWavesPerBlock), 0, s, a, nframes);
+    const dim3 grid((a.ntiles + kXTiles - 1) / kXTiles, nframes);
+    hipLaunchKernelGGL(k_expand, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
