@@ -416,7 +416,7 @@ __device__ __forceinline__ int kth_set_bit(uint64_t mask, uint32_t k) {
 constexpr uint32_t kXTiles = MI355_XTILES;   // tiles per workgroup (power of two, <= 64)
 constexpr int kXLog = kXTiles == 64 ? 6 : kXTiles == 32 ? 5 : kXTiles == 16 ? 4 : 3;
 #ifndef MI355_XROUNDS
-#define MI355_XROUNDS 4
+#define MI355_XROUNDS 3
 #endif
 constexpr int kXRounds = MI355_XROUNDS;   // rounds of 256 records per pass (even)
 constexpr uint32_t kXEntries = 3072;    // entries staged in LDS per workgroup; denser workgroups store directly
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
     __shared__ uint64_t s_mask[kXTiles];
     __shared__ uint32_t s_rincl[kXTiles];                 // inclusive prefix of records per tile
     __shared__ uint32_t s_rpos[kXTiles];                  // log position of the tile's first record
-    __shared__ uint32_t s_wave[4][kXRounds / 2];          // per wave: packed byte totals per round pair
+    __shared__ uint32_t s_wave[4][(kXRounds + 1) / 2];    // per wave: packed byte totals per round pair
     __shared__ uint32_t s_total;                          // entries of this workgroup
     __shared__ int32_t s_xs[kXEntries];
     __shared__ uint8_t s_df[kXEntries];
@@ -433,6 +433,8 @@ __global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
     const uint32_t tile0 = blockIdx.x * kXTiles;
     const size_t row = (size_t)t * a.ntiles;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // issued first: needed only when the entries leave, so their latency hides behind everything else
+    const uint32_t dst0 = a.offsets[t] + a.segoff[row + tile0];   // < 2^32: the batch total is below 2^32
 
     if (wave == 0) {   // all 64 lanes take part in the DPP scans; lanes >= kXTiles carry zeros
         const uint32_t tile = tile0 + (uint32_t)lane;
@@ -453,7 +455,6 @@ __global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
     if (nrec == 0) return;
     const uint32_t total = s_total;
     const bool staged = total <= kXEntries;
-    const uint32_t dst0 = a.offsets[t] + a.segoff[row + tile0];   // < 2^32: the batch total is below 2^32
 
     uint32_t carry = 0;   // entries of earlier passes
     for (uint32_t base = 0; base < nrec; base += 256 * kXRounds) {
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
         }
         // 16-bit maps of the nonzero (= flagged) bytes: v_dot4 gathers the four 0x80 marks of a dword
         // into 4 adjacent bits
-        uint32_t m16[kXRounds], cnt[kXRounds], incl[kXRounds / 2];
+        uint32_t m16[kXRounds], cnt[kXRounds], incl[(kXRounds + 1) / 2];
 #pragma unroll
         for (int j = 0; j < kXRounds; j++) {
             const uint32_t g0 = __builtin_amdgcn_udot4(nonzero_bytes(rec[j].x), 0x08040201u, 0u, false);
@@ -491,8 +492,9 @@ __global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
             cnt[j] = (uint32_t)__builtin_popcount(m16[j]);
         }
 #pragma unroll
-        for (int j = 0; j < kXRounds / 2; j++) {      // a round total is at most 256*16 = 4096
-            incl[j] = (uint32_t)wave_inclusive_scan((int)(cnt[2 * j] | (cnt[2 * j + 1] << 16)));
+        for (int j = 0; j < (kXRounds + 1) / 2; j++) {      // a round total is at most 256*16 = 4096
+            const uint32_t hi = 2 * j + 1 < kXRounds ? cnt[(2 * j + 1) % kXRounds] : 0u;
+            incl[j] = (uint32_t)wave_inclusive_scan((int)(cnt[2 * j] | (hi << 16)));
             if (lane == 63) s_wave[wave][j] = incl[j];
         }
         __syncthreads();
