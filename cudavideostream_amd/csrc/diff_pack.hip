@@ -59,6 +59,12 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
     return v;
 }
 
+// v_writelane_b32: put a wave-uniform value into one lane of a VGPR (1 instruction instead of
+// v_mov + v_cndmask); `lane` must be a compile-time constant here.
+__device__ __forceinline__ void write_lane(uint32_t &v, uint32_t uniform_value, int lane) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(uniform_value), "n"(lane));
+}
+
 // ---- per-dword byte arithmetic (4 bytes per instruction) --------------------------------------------
 constexpr uint32_t kH = 0x80808080u, kL = 0x7f7f7f7fu;
 
@@ -126,16 +132,19 @@ __device__ __forceinline__ void store16_bytes(uint8_t *p, uint4 v, int valid) {
 #endif
 template <bool FAST, bool NT = false>
 __device__ __forceinline__ uint4 load16(const uint8_t *p, int valid) {
-    if (FAST && NT) {
-#if MI355_NT_LOADS
+    if (FAST) {
+        // every frame / state pointer of this kernel is global memory: say so, or a pointer rebuilt
+        // from scalar halves (uniform_ptr) would be loaded through the flat aperture
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-        return make_uint4(v.x, v.y, v.z, v.w);
+        typedef const __attribute__((address_space(1))) u32x4 *gptr;
+        const gptr g = (gptr)(uintptr_t)p;
+#if MI355_NT_LOADS
+        const u32x4 v = NT ? __builtin_nontemporal_load(g) : *g;
 #else
-        return *reinterpret_cast<const uint4 *>(p);
+        const u32x4 v = *g;
 #endif
+        return make_uint4(v.x, v.y, v.z, v.w);
     }
-    if (FAST) return *reinterpret_cast<const uint4 *>(p);
     return load16_bytes(p, valid);
 }
 
@@ -198,19 +207,33 @@ __device__ __forceinline__ uint64_t pack_step(const uint4 c, uint4 &s, ThrConst 
 // (frame index clamped to T-1) so that the number of vector-memory operations younger than any
 // load is known at compile time: on gfx950 loads and stores share one in-order vmcnt, and a
 // conditional load would make the compiler fall back to s_waitcnt vmcnt(0) -- i.e. no prefetch.
+// Tells the compiler a pointer is wave-uniform (it is: kernel arguments and the frame counter only), so
+// that it stays in SGPRs and the access uses the SGPR-base + VGPR-offset addressing form.
+__device__ __forceinline__ const uint8_t *uniform_ptr(const uint8_t *p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (const uint8_t *)(((uint64_t)hi << 32) | lo);
+}
+
 template <bool PAIR, bool FAST>
 struct Group {
     uint4 c[kPrefetch];
     uint4 p[kPrefetch];
 
-    __device__ __forceinline__ void load(const PackArgs &a, const uint8_t *cp, const uint8_t *pp, int t0,
-                                         int valid) {
+    // The frame base (a.cur + t*stride) is wave-uniform and the lane's byte offset is a 32-bit VGPR:
+    // the loads use the SGPR-base + VGPR-offset form and need no per-lane 64-bit address arithmetic.
+    __device__ __forceinline__ void load(const PackArgs &a, uint32_t byte_off, int t0, int valid) {
         const int last = a.nframes - 1;
 #pragma unroll
         for (int d = 0; d < kPrefetch; d++) {
             const int t = min(t0 + d, last);
-            c[d] = load16<FAST, !PAIR>(cp + (size_t)t * a.stride, valid);   // stream frames: read once
-            if (PAIR) p[d] = load16<FAST>(pp + (size_t)t * a.stride, valid);
+            const uint8_t *cb = uniform_ptr(a.cur + (size_t)t * a.stride);
+            c[d] = load16<FAST, !PAIR>(cb + byte_off, valid);   // stream frames: read once
+            if (PAIR) {
+                const uint8_t *pb = uniform_ptr(a.prev + (size_t)t * a.stride);
+                p[d] = load16<FAST>(pb + byte_off, valid);
+            }
         }
     }
 };
@@ -243,8 +266,15 @@ __device__ __forceinline__ void pack_group(const PackArgs &a, const Group<PAIR, 
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane(
             wave_inclusive_scan((int)(c0 | (c1 << 16))), 63);
         const uint32_t n0 = ((tot & 0xffffu) - 64u * 24u) >> 2, n1 = ((tot >> 16) - 64u * 24u) >> 2;
-        if (lane == d) meta = make_uint4((uint32_t)m0, (uint32_t)(m0 >> 32), n0, run0);
-        if (lane == d + 1) meta = make_uint4((uint32_t)m1, (uint32_t)(m1 >> 32), n1, run1);
+        // all four values are wave-uniform: v_writelane drops them into lanes d and d+1
+        write_lane(meta.x, (uint32_t)m0, d);
+        write_lane(meta.y, (uint32_t)(m0 >> 32), d);
+        write_lane(meta.z, n0, d);
+        write_lane(meta.w, run0, d);
+        write_lane(meta.x, (uint32_t)m1, d + 1);
+        write_lane(meta.y, (uint32_t)(m1 >> 32), d + 1);
+        write_lane(meta.z, n1, d + 1);
+        write_lane(meta.w, run1, d + 1);
     }
     if (lane < kPrefetch && t0 + lane < a.nframes && MI355_ABLATE != 2 && MI355_ABLATE != 3)
         a.meta[(size_t)(t0 + lane) * a.ntiles + tile] = meta;
@@ -254,8 +284,6 @@ template <bool PAIR, bool FAST>
 __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint32_t byte_off,
                                           int valid, int lane) {
     const int T = a.nframes;
-    const uint8_t *cp = a.cur + byte_off;
-    const uint8_t *pp = PAIR ? a.prev + byte_off : nullptr;
     const ThrConst tc{(127u - (uint32_t)a.thr) * 0x01010101u, (uint32_t)a.thr * 0x01010101u};
 
     uint4 st = make_uint4(0, 0, 0, 0);
@@ -266,13 +294,13 @@ __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint
     // exact s_waitcnt vmcnt(kPrefetch).
     Group<PAIR, FAST> ga, gb;
     uint32_t run = 0;  // records this tile has appended to its log so far
-    ga.load(a, cp, pp, 0, valid);
+    ga.load(a, byte_off, 0, valid);
     for (int t0 = 0;;) {
-        gb.load(a, cp, pp, t0 + kPrefetch, valid);
+        gb.load(a, byte_off, t0 + kPrefetch, valid);
         pack_group<PAIR, FAST>(a, ga, t0, st, run, tile, tc, lane);
         t0 += kPrefetch;
         if (t0 >= T) break;
-        ga.load(a, cp, pp, t0 + kPrefetch, valid);
+        ga.load(a, byte_off, t0 + kPrefetch, valid);
         pack_group<PAIR, FAST>(a, gb, t0, st, run, tile, tc, lane);
         t0 += kPrefetch;
         if (t0 >= T) break;
