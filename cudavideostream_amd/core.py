@@ -164,6 +164,40 @@ class CUDACore:
         _l.check(self._lib.mi355_diff_pairs_batch(self._h, _ptr(d_cur), _ptr(d_prev), stride, nframes,
                                                   _ptr(d_offsets), _ptr(d_xs), _ptr(d_diff), capacity))
 
+    # -- the stream either side of the path (wire format, client, row-band merge) -------------------
+    def diff_stream_wire_batch(self, d_frames, nframes, d_offsets, d_wire, capacity_bytes, stride=None):
+        """threads.cpp:227-229 byte stream of the batch: {u32 n, i32 xs[n], u8 diff[n]} per frame."""
+        stride = self.total if stride is None else stride
+        _l.check(self._lib.mi355_diff_stream_wire_batch(self._h, _ptr(d_frames), stride, nframes,
+                                                        _ptr(d_offsets), _ptr(d_wire), capacity_bytes))
+
+    def wire_bytes(self, nframes, entries):
+        return self._lib.mi355_wire_bytes(nframes, entries)
+
+    def apply_batch(self, d_offsets, d_xs, d_diff, nframes, d_frames_out=None, stride=None):
+        """client/opencv.cpp:64-66 on this core's state, frame by frame."""
+        stride = self.total if stride is None else stride
+        _l.check(self._lib.mi355_apply_batch(self._h, _ptr(d_offsets), _ptr(d_xs), _ptr(d_diff), nframes,
+                                             _ptr(d_frames_out), stride))
+
+    def apply_wire_batch(self, d_wire, counts, nframes, d_frames_out=None, stride=None):
+        stride = self.total if stride is None else stride
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        assert counts.size >= nframes
+        _l.check(self._lib.mi355_apply_wire_batch(self._h, _ptr(d_wire), counts.ctypes.data, nframes,
+                                                  _ptr(d_frames_out), stride))
+
+    def merge_parts(self, d_part_offsets, part_base, xs_bias, d_xs_all, d_diff_all, nframes, d_offsets, d_xs,
+                    d_diff, capacity):
+        """Row-band streams of one video stream -> the stream of the whole frame."""
+        part_base = np.ascontiguousarray(part_base, dtype=np.uint32)
+        xs_bias = np.ascontiguousarray(xs_bias, dtype=np.int32)
+        assert part_base.size == xs_bias.size
+        _l.check(self._lib.mi355_merge_parts(self._h, part_base.size, nframes, _ptr(d_part_offsets),
+                                             part_base.ctypes.data, xs_bias.ctypes.data, _ptr(d_xs_all),
+                                             _ptr(d_diff_all), _ptr(d_offsets), _ptr(d_xs), _ptr(d_diff),
+                                             capacity))
+
     def int_diff(self, d_cur, d_prev, d_out, n):
         _l.check(self._lib.mi355_int_diff(self._h, _ptr(d_cur), _ptr(d_prev), _ptr(d_out), n))
 

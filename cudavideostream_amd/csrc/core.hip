@@ -128,8 +128,10 @@ void build_heat_lut(uint8_t *lut) {
     }
 }
 
+// d_wire != nullptr: the expander writes the sender's byte stream (capacity in bytes) instead of d_xs/d_diff.
 int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, size_t stride,
-              int nframes, void *d_offsets, void *d_xs, void *d_diff, size_t capacity) {
+              int nframes, void *d_offsets, void *d_xs, void *d_diff, size_t capacity,
+              void *d_wire = nullptr) {
     if (!c) return fail(MI355_ERR_INVALID, "null core");
     if (nframes < 0 || nframes > c->cfg.max_batch)
         return fail(MI355_ERR_INVALID, "nframes outside [0, max_batch]");
@@ -137,10 +139,14 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     if (nframes > 0 && c->n > 0 && (!d_cur || (pair && !d_prev)))
         return fail(MI355_ERR_INVALID, "null frame pointer");
     if (nframes > 0 && stride < c->n) return fail(MI355_ERR_INVALID, "stride_bytes < frame bytes");
-    if (capacity > 0 && (!d_xs || !d_diff)) return fail(MI355_ERR_INVALID, "null output pointer");
+    if (capacity > 0 && !d_wire && (!d_xs || !d_diff)) return fail(MI355_ERR_INVALID, "null output pointer");
     if (int rc = use_device(c)) return rc;
     if (nframes == 0 || c->n == 0) {
         HIP_TRY(hipMemsetAsync(d_offsets, 0, sizeof(uint32_t) * ((size_t)nframes + 1), c->stream));
+        if (d_wire) {   // empty frames still have their headers {n = 0}
+            const size_t head = 4 * (size_t)nframes < capacity ? 4 * (size_t)nframes : capacity & ~(size_t)3;
+            if (head) HIP_TRY(hipMemsetAsync(d_wire, 0, head, c->stream));
+        }
         return MI355_OK;
     }
     hipEvent_t *tev = nullptr;
@@ -173,6 +179,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     g.ntiles = c->ntiles;
     g.out_xs = (int32_t *)d_xs;
     g.out_diff = (uint8_t *)d_diff;
+    g.wire = (uint8_t *)d_wire;
     g.capacity = capacity;
     HIP_TRY(launch_expand(g, nframes, c->stream));
     if (tev) {
@@ -338,6 +345,86 @@ int mi355_diff_stream_batch(mi355_core *c, const void *d_frames, size_t stride_b
 int mi355_diff_pairs_batch(mi355_core *c, const void *d_cur, const void *d_prev, size_t stride_bytes,
                            int nframes, void *d_offsets, void *d_xs, void *d_diff, size_t capacity) {
     return run_batch(c, true, d_cur, d_prev, stride_bytes, nframes, d_offsets, d_xs, d_diff, capacity);
+}
+
+int mi355_diff_stream_wire_batch(mi355_core *c, const void *d_frames, size_t stride_bytes, int nframes,
+                                 void *d_offsets, void *d_wire, size_t capacity_bytes) {
+    if (!d_wire) return fail(MI355_ERR_INVALID, "null d_wire");
+    return run_batch(c, false, d_frames, nullptr, stride_bytes, nframes, d_offsets, nullptr, nullptr,
+                     capacity_bytes, d_wire);
+}
+
+size_t mi355_wire_bytes(int nframes, uint64_t entries) { return 4 * (size_t)nframes + 5 * (size_t)entries; }
+
+int mi355_apply_batch(mi355_core *c, const void *d_offsets, const void *d_xs, const void *d_diff, int nframes,
+                      void *d_frames_out, size_t stride_bytes) {
+    if (!c) return fail(MI355_ERR_INVALID, "null core");
+    if (nframes < 0) return fail(MI355_ERR_INVALID, "nframes < 0");
+    if (nframes == 0 || c->n == 0) return MI355_OK;
+    if (!d_offsets || !d_xs || !d_diff) return fail(MI355_ERR_INVALID, "null stream pointer");
+    if (d_frames_out && stride_bytes < c->n) return fail(MI355_ERR_INVALID, "stride_bytes < frame bytes");
+    if (int rc = use_device(c)) return rc;
+    if (!d_frames_out) {
+        HIP_TRY(launch_apply_all(c->state, c->n, (const int32_t *)d_xs, (const uint8_t *)d_diff,
+                                 (const uint32_t *)d_offsets, nframes, c->stream));
+        return MI355_OK;
+    }
+    for (int t = 0; t < nframes; t++) {
+        HIP_TRY(launch_apply(c->state, c->n, d_xs, d_diff, (const uint32_t *)d_offsets, t, 0, c->stream));
+        HIP_TRY(hipMemcpyAsync((uint8_t *)d_frames_out + (size_t)t * stride_bytes, c->state, c->n,
+                               hipMemcpyDeviceToDevice, c->stream));
+    }
+    return MI355_OK;
+}
+
+int mi355_apply_wire_batch(mi355_core *c, const void *d_wire, const uint32_t *h_counts, int nframes,
+                           void *d_frames_out, size_t stride_bytes) {
+    if (!c) return fail(MI355_ERR_INVALID, "null core");
+    if (nframes < 0) return fail(MI355_ERR_INVALID, "nframes < 0");
+    if (nframes == 0) return MI355_OK;
+    if (!d_wire || !h_counts) return fail(MI355_ERR_INVALID, "null stream pointer");
+    if (d_frames_out && stride_bytes < c->n) return fail(MI355_ERR_INVALID, "stride_bytes < frame bytes");
+    if (int rc = use_device(c)) return rc;
+    const uint8_t *p = (const uint8_t *)d_wire;
+    for (int t = 0; t < nframes; t++) {
+        const uint32_t cnt = h_counts[t];
+        if (cnt > c->n) return fail(MI355_ERR_INVALID, "frame count larger than the frame");
+        const uint8_t *xs = p + 4, *df = xs + 4 * (size_t)cnt;   // opencv.cpp:52-62
+        HIP_TRY(launch_apply(c->state, c->n, xs, df, nullptr, 0, cnt, c->stream));
+        if (d_frames_out && c->n)
+            HIP_TRY(hipMemcpyAsync((uint8_t *)d_frames_out + (size_t)t * stride_bytes, c->state, c->n,
+                                   hipMemcpyDeviceToDevice, c->stream));
+        p = df + cnt;
+    }
+    return MI355_OK;
+}
+
+int mi355_merge_parts(mi355_core *c, int nparts, int nframes, const void *d_part_offsets,
+                      const uint32_t *h_part_base, const int32_t *h_xs_bias, const void *d_xs_all,
+                      const void *d_diff_all, void *d_offsets, void *d_xs, void *d_diff, size_t capacity) {
+    if (!c) return fail(MI355_ERR_INVALID, "null core");
+    if (nparts < 1 || nparts > kMaxParts) return fail(MI355_ERR_INVALID, "nparts outside [1, 64]");
+    if (nframes < 0) return fail(MI355_ERR_INVALID, "nframes < 0");
+    if (!d_part_offsets || !h_part_base || !h_xs_bias || !d_offsets)
+        return fail(MI355_ERR_INVALID, "null argument");
+    if (capacity > 0 && (!d_xs_all || !d_diff_all || !d_xs || !d_diff))
+        return fail(MI355_ERR_INVALID, "null stream pointer");
+    if (int rc = use_device(c)) return rc;
+    MergeArgs a{};
+    a.part_off = (const uint32_t *)d_part_offsets;
+    a.xs_all = (const int32_t *)d_xs_all;
+    a.diff_all = (const uint8_t *)d_diff_all;
+    a.out_xs = (int32_t *)d_xs;
+    a.out_diff = (uint8_t *)d_diff;
+    a.capacity = capacity;
+    a.nparts = nparts;
+    a.nframes = nframes;
+    for (int p = 0; p < nparts; p++) {
+        a.part_base[p] = h_part_base[p];
+        a.xs_bias[p] = h_xs_bias[p];
+    }
+    HIP_TRY(launch_merge(a, (uint32_t *)d_offsets, c->stream));
+    return MI355_OK;
 }
 
 int mi355_int_diff(mi355_core *c, const void *d_cur, const void *d_prev, void *d_out, size_t n) {

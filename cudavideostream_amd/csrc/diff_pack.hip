@@ -449,6 +449,12 @@ constexpr int kXLog = kXTiles == 64 ? 6 : kXTiles == 32 ? 5 : kXTiles == 16 ? 4 
 constexpr int kXRounds = MI355_XROUNDS;   // rounds of 256 records per pass (even)
 constexpr uint32_t kXEntries = 3072;    // entries staged in LDS per workgroup; denser workgroups store directly
 
+// WIRE: the entries leave in the sender's byte stream instead (server/src/threads.cpp:227-229): frame t
+// is {u32 n, i32 xs[n], u8 diff[n]} at byte 4t + 5*offsets[t] of a.wire, so index and payload sections
+// start at arbitrary byte addresses (gfx950 global stores need no alignment).
+__device__ __forceinline__ void store_u32_unaligned(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
+template <bool WIRE>
 __global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
     __shared__ uint64_t s_mask[kXTiles];
     __shared__ uint32_t s_rincl[kXTiles];                 // inclusive prefix of records per tile
@@ -462,7 +468,20 @@ __global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
     const size_t row = (size_t)t * a.ntiles;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // issued first: needed only when the entries leave, so their latency hides behind everything else
-    const uint32_t dst0 = a.offsets[t] + a.segoff[row + tile0];   // < 2^32: the batch total is below 2^32
+    const uint32_t off_t = a.offsets[t];
+    const uint32_t dst0 = off_t + a.segoff[row + tile0];   // < 2^32: the batch total is below 2^32
+    uint8_t *w_xs = nullptr, *w_df = nullptr;   // WIRE: this workgroup's first index / payload byte
+    size_t w_room = 0;                          // WIRE: entries of this workgroup that fit in a.capacity bytes
+    if (WIRE) {
+        const uint32_t n_t = a.offsets[t + 1] - off_t;
+        const size_t head = 4 * (size_t)t + 5 * (size_t)off_t;
+        const size_t end = head + 4 + 5 * (size_t)n_t;   // a frame is written whole or (payload) not at all
+        if (blockIdx.x == 0 && threadIdx.x == 0 && head + 4 <= a.capacity) store_u32_unaligned(a.wire + head, n_t);
+        const uint32_t seg = dst0 - off_t;
+        w_xs = a.wire + head + 4 + 4 * (size_t)seg;
+        w_df = a.wire + head + 4 + 4 * (size_t)n_t + seg;
+        w_room = end <= a.capacity ? (size_t)n_t : 0;
+    }
 
     if (wave == 0) {   // all 64 lanes take part in the DPP scans; lanes >= kXTiles carry zeros
         const uint32_t tile = tile0 + (uint32_t)lane;
@@ -549,6 +568,11 @@ __global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
                 if (staged) {
                     s_xs[e] = xs;
                     s_df[e] = df;
+                } else if (WIRE) {
+                    if (w_room) {
+                        store_u32_unaligned(w_xs + 4 * (size_t)e, (uint32_t)xs);
+                        w_df[e] = df;
+                    }
                 } else if ((size_t)dst0 + e < a.capacity) {
                     a.out_xs[dst0 + e] = xs;
                     a.out_diff[dst0 + e] = df;
@@ -561,7 +585,12 @@ __global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
     }
     if (staged) {
         for (uint32_t e = threadIdx.x; e < total; e += 256) {
-            if ((size_t)dst0 + e < a.capacity) {
+            if (WIRE) {
+                if (w_room) {
+                    store_u32_unaligned(w_xs + 4 * (size_t)e, (uint32_t)s_xs[e]);
+                    w_df[e] = s_df[e];
+                }
+            } else if ((size_t)dst0 + e < a.capacity) {
                 a.out_xs[dst0 + e] = s_xs[e];
                 a.out_diff[dst0 + e] = s_df[e];
             }
@@ -571,7 +600,10 @@ __global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
 
 hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s) {
     const dim3 grid((a.ntiles + kXTiles - 1) / kXTiles, nframes);
-    hipLaunchKernelGGL(k_expand, grid, dim3(256), 0, s, a);
+    if (a.wire)
+        hipLaunchKernelGGL(k_expand<true>, grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_expand<false>, grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -34,7 +34,8 @@ struct ExpandArgs {
     uint32_t ntiles;
     int32_t *out_xs;
     uint8_t *out_diff;
-    size_t capacity;
+    uint8_t *wire;            // != nullptr: write the sender's byte stream here instead of out_xs/out_diff
+    size_t capacity;          // entries of out_xs/out_diff, or bytes of wire
 };
 
 // diff_pack.hip
@@ -42,6 +43,25 @@ hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, hipStrea
 hipError_t launch_scan(const uint4 *meta, uint32_t *segoff, uint32_t *totals, uint32_t ntiles,
                        int nframes, uint32_t *offsets, hipStream_t s);
 hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s);
+
+// stream_ops.hip
+constexpr int kMaxParts = 64;
+struct MergeArgs {
+    const uint32_t *part_off;   // [nparts][T+1] device: each part's own exclusive scan
+    const int32_t *xs_all;      // parts' entries back to back, part p at part_base[p]
+    const uint8_t *diff_all;
+    int32_t *out_xs;
+    uint8_t *out_diff;
+    size_t capacity;
+    int32_t nparts, nframes;
+    uint32_t part_base[kMaxParts];
+    int32_t xs_bias[kMaxParts];
+};
+hipError_t launch_apply(uint8_t *frame, uint32_t nbytes, const void *xs, const void *diff,
+                        const uint32_t *d_offsets, int t, uint32_t host_count, hipStream_t s);
+hipError_t launch_apply_all(uint8_t *frame, uint32_t nbytes, const int32_t *xs, const uint8_t *diff,
+                            const uint32_t *d_offsets, int nframes, hipStream_t s);
+hipError_t launch_merge(const MergeArgs &a, uint32_t *out_offsets, hipStream_t s);
 
 // filters.hip -- every per-frame kernel takes a FrameBatch: frame f lives at base + f*stride
 struct FrameBatch {

@@ -69,3 +69,41 @@ def gather_payload(offsets, xs, diff, dst=0):
         for w in dist.batch_isend_irecv(ops):
             w.wait()
     return totals, None, None, None
+
+
+# ---- E2: one stream split into row bands ------------------------------------------
+def band_rows(rank, world, height):
+    """Rows [first, last) of the band rank `rank` owns; bands are contiguous byte ranges of the frame."""
+    return height * rank // world, height * (rank + 1) // world
+
+
+def gather_bands(offsets, xs, diff, band_first_byte, core=None, dst=0):
+    """Every rank packed its row band of the SAME frames (a core of the band's height fed with
+    frames + band_first_byte, stride = whole-frame bytes).  Gathers the bands to dst and, when `core`
+    is given there, merges them on the device (mi355_merge_parts) into the stream of the whole frame.
+
+    Returns on dst (offsets[T+1], xs, diff) of the merged stream when core is given, else the raw pieces
+    (index[world, T+1], part_base, xs_bias, xs_all, diff_all); (None,)*3 on the other ranks."""
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    b_local = torch.tensor([int(band_first_byte)], dtype=torch.int64, device=offsets.device)
+    if world > 1:
+        b_all = [torch.zeros_like(b_local) for _ in range(world)]
+        dist.all_gather(b_all, b_local)
+        xs_bias = [int(b.item()) for b in b_all]
+    else:
+        xs_bias = [int(band_first_byte)]
+    totals, xs_all, df_all, index = gather_payload(offsets, xs, diff, dst)
+    if rank != dst:
+        return None, None, None
+    part_base = [sum(totals[:p]) for p in range(world)]
+    if core is None:
+        return index, part_base, xs_bias, xs_all, df_all
+    nframes = offsets.numel() - 1
+    total = sum(totals)
+    out_off = torch.empty_like(offsets)
+    out_xs = torch.empty(max(total, 1), dtype=xs.dtype, device=xs.device)
+    out_df = torch.empty(max(total, 1), dtype=diff.dtype, device=diff.device)
+    core.merge_parts(index.contiguous(), part_base, xs_bias, xs_all, df_all, nframes, out_off, out_xs, out_df,
+                     total)
+    return out_off, out_xs[:total], out_df[:total]

@@ -53,6 +53,14 @@ SYMBOLS = {
                                           C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi355_diff_pairs_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi355_diff_stream_wire_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
+                                               C.c_void_p, C.c_size_t]),
+    "mi355_wire_bytes": (C.c_size_t, [C.c_int, C.c_uint64]),
+    "mi355_apply_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_size_t]),
+    "mi355_apply_wire_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "mi355_merge_parts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi355_int_diff": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi355_gray_avg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi355_gray_weighted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -104,6 +104,39 @@ int mi355_diff_pairs_batch(mi355_core *core, const void *d_cur, const void *d_pr
                            size_t stride_bytes, int nframes, void *d_offsets, void *d_xs,
                            void *d_diff, size_t capacity);
 
+/* ---- the stream either side of the path ---------------------------------------
+ * Wire form of mi355_diff_stream_batch: instead of separate (xs, diff) arrays the batch leaves as the exact
+ * byte stream the reference's sender thread writes per frame (server/src/threads.cpp:227-229):
+ *     u32 n (= h_pos) | i32 xs[n] | u8 diff[n]
+ * frames back to back, frame t at byte 4*t + 5*offsets[t] of d_wire; mi355_wire_bytes(nframes,
+ * offsets[nframes]) bytes in all, ready for one write() to the socket after the base frame
+ * (threads.cpp:224, mi355_get_state before the first batch).  A frame that does not fit in capacity_bytes
+ * is dropped whole (its header is still written when it fits); d_offsets is exact regardless. */
+int mi355_diff_stream_wire_batch(mi355_core *core, const void *d_frames, size_t stride_bytes, int nframes,
+                                 void *d_offsets, void *d_wire, size_t capacity_bytes);
+size_t mi355_wire_bytes(int nframes, uint64_t entries);
+
+/* The client's side, client/opencv.cpp:50-66: for every frame in order, state[xs[i]] += diff[i] (uint8
+ * wrap-around) on the core's state (a client core is a core whose state was set to the received base frame,
+ * opencv.cpp:38-46).  d_frames_out != NULL: the reconstructed frame t is also copied to d_frames_out +
+ * t*stride_bytes (what the client shows, opencv.cpp:68); NULL: only the state advances, all frames in one
+ * launch.  Indices >= N are ignored.  Asynchronous on the core's stream. */
+int mi355_apply_batch(mi355_core *core, const void *d_offsets, const void *d_xs, const void *d_diff,
+                      int nframes, void *d_frames_out, size_t stride_bytes);
+/* Same from the wire bytes; h_counts[t] (host) are the headers the client has read from the socket
+ * (opencv.cpp:52), the header words inside d_wire are skipped, not trusted. */
+int mi355_apply_wire_batch(mi355_core *core, const void *d_wire, const uint32_t *h_counts, int nframes,
+                           void *d_frames_out, size_t stride_bytes);
+
+/* Several cores may each own a row band of ONE stream (bands are contiguous byte ranges of the frame, so a
+ * band is a core of the band's height fed with d_frames + band_start).  After the
+ * bands' streams have been gathered back to back (part p's entries at h_part_base[p], its own index
+ * d_part_offsets[p][0..nframes]), this merges them into the single stream of the whole frame: frame t =
+ * the parts' frame-t segments in part order, xs + h_xs_bias[p] (the band's first byte). */
+int mi355_merge_parts(mi355_core *core, int nparts, int nframes, const void *d_part_offsets,
+                      const uint32_t *h_part_base, const int32_t *h_xs_bias, const void *d_xs_all,
+                      const void *d_diff_all, void *d_offsets, void *d_xs, void *d_diff, size_t capacity);
+
 /* Integer difference of tests/algorithms_benchmarks.cu:24-30 (kernel1): d[i] = cur[i] - prev[i] on
  * int32 arrays of n elements, no threshold, no pack. */
 int mi355_int_diff(mi355_core *core, const void *d_cur, const void *d_prev, void *d_out, size_t n);

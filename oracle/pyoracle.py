@@ -130,6 +130,38 @@ def client_apply(frame, xs, diff):
     return out
 
 
+def wire_pack(offsets, xs, diff):
+    """Bytes the sender thread writes for the frames of a packed stream, server/src/threads.cpp:227-229:
+    per frame write(h_pos, 4) ; write(h_xs, h_pos*4) ; write(frame data, h_pos)."""
+    offsets = np.asarray(offsets).astype(np.int64)
+    out = []
+    for t in range(offsets.size - 1):
+        a, b = offsets[t], offsets[t + 1]
+        out.append(np.uint32(b - a).tobytes())
+        out.append(np.ascontiguousarray(xs[a:b], dtype=np.int32).tobytes())
+        out.append(np.ascontiguousarray(diff[a:b], dtype=np.uint8).tobytes())
+    return np.frombuffer(b"".join(out), np.uint8).copy()
+
+
+def wire_client(base, wire, nframes):
+    """The client's receive loop, client/opencv.cpp:50-66: read pos, pos ints, pos bytes; then
+    frame2.data[xs[i]] += buffer[i].  Returns (frames (nframes, n) as displayed, counts)."""
+    frame = _u8(base).copy()
+    wire = _u8(wire)
+    at = 0
+    frames = np.empty((nframes, frame.size), np.uint8)
+    counts = np.empty(nframes, np.uint32)
+    for t in range(nframes):
+        pos = int(wire[at:at + 4].view(np.uint32)[0]); at += 4
+        xs = wire[at:at + 4 * pos].copy().view(np.int32); at += 4 * pos
+        buf = wire[at:at + pos]; at += pos
+        lib().ora_client_apply(frame, xs, np.ascontiguousarray(buf), pos)
+        frames[t] = frame
+        counts[t] = pos
+    assert at == wire.size
+    return frames, counts
+
+
 def gaussian_kernel(K=3, sigma=1.5):
     k = np.zeros(K * K, np.float32)
     lib().ora_gaussian_kernel(k, K, sigma)

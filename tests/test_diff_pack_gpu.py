@@ -4,12 +4,12 @@ import numpy as np
 import pytest
 
 from conftest import golden
-from cudavideostream_amd import CUDACore, lib, synth
+from cudavideostream_amd import lib, synth
 
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
-from gpu_util import DEV, oracle_pairs, run_stream, to_dev  # noqa: E402
+from gpu_util import DEV, CUDACore, oracle_pairs, run_stream, to_dev  # noqa: E402
 
 
 def check_stream(po, core, base, frames, thr=20, **kw):

@@ -5,12 +5,12 @@ import numpy as np
 import pytest
 
 from conftest import golden
-from cudavideostream_amd import CUDACore, lib, synth
+from cudavideostream_amd import lib, synth
 
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
-from gpu_util import DEV, to_dev  # noqa: E402
+from gpu_util import DEV, CUDACore, to_dev  # noqa: E402
 
 
 def dev_out(n):

@@ -82,6 +82,65 @@ def test_gather_payload_and_index(world):
         at += totals[r]
 
 
+def _band_stream(rank, world, T, w, h):
+    from oracle import pyoracle as po
+    base, frames = synth.webcam_stream(T, w, h, seed=33)
+    r0, r1 = gx.band_rows(rank, world, h)
+    b0, b1 = 3 * w * r0, 3 * w * r1
+    return b0, po.diff_stream(np.ascontiguousarray(frames[:, b0:b1]), base[b0:b1])
+
+
+def _band_worker(rank, world, port, T, w, h, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b0, (off, xs, df, _) = _band_stream(rank, world, T, w, h)
+        t_off = torch.from_numpy(off.view(np.int32).copy())
+        t_xs = torch.from_numpy(np.append(xs, np.int32(0)))
+        t_df = torch.from_numpy(np.append(df, np.uint8(0)))
+        out = gx.gather_bands(t_off, t_xs, t_df, b0, core=None, dst=0)
+        if rank == 0:
+            index, part_base, xs_bias, xs_all, df_all = out
+            q.put((index.numpy().copy(), part_base, xs_bias, xs_all.numpy().copy(), df_all.numpy().copy()))
+        else:
+            assert out == (None, None, None)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_bands_of_one_stream_gather_to_the_whole_frame_stream(world):
+    """E2 of SURVEY.md section 8e: ranks own row bands of the same frames; the gathered pieces, merged in
+    band order with the bands' byte offsets (what mi355_merge_parts does on the device, checked against
+    this same rule in tests/test_stream_ops_gpu.py), are the whole-frame stream of the oracle."""
+    from oracle import pyoracle as po
+    T, w, h = 5, 40, 21
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_band_worker, args=(r, world, port, T, w, h, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    index, part_base, xs_bias, xs_all, df_all = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    base, frames = synth.webcam_stream(T, w, h, seed=33)
+    off, xs, df, _ = po.diff_stream(frames, base)
+    assert xs_bias == [3 * w * gx.band_rows(r, world, h)[0] for r in range(world)]
+    idx = index.view(np.uint32).astype(np.int64)
+    m_xs, m_df, m_off = [], [], [0]
+    for t in range(T):
+        for p in range(world):
+            seg = slice(part_base[p] + idx[p, t], part_base[p] + idx[p, t + 1])
+            m_xs.append(xs_all[seg] + xs_bias[p]); m_df.append(df_all[seg])
+        m_off.append(m_off[-1] + int((idx[:, t + 1] - idx[:, t]).sum()))
+    assert np.array_equal(np.array(m_off, np.uint32), off)
+    assert np.array_equal(np.concatenate(m_xs), xs)
+    assert np.array_equal(np.concatenate(m_df), df)
+
+
 def test_single_process_passthrough():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     dist.init_process_group("gloo", rank=0, world_size=1)

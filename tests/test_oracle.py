@@ -241,3 +241,29 @@ def test_synth_properties(po):
     torch = pytest.importorskip("torch")
     tb, tf = synth.webcam_stream(2, 192, 108, device="cpu")
     assert np.array_equal(tb.numpy(), base) and np.array_equal(tf.numpy(), frames[:2])
+
+
+def test_wire_format_and_client_round_trip(po):
+    """server/src/threads.cpp:227-229 (sender) and client/opencv.cpp:50-66 (receiver) restated: layout of a
+    hand-made stream, and client == server state after a seeded stream."""
+    off = np.array([0, 2, 2, 3], np.uint32)
+    xs = np.array([1, 7, 4], np.int32)
+    df = np.array([200, 3, 255], np.uint8)
+    wire = po.wire_pack(off, xs, df)
+    want = (b"\x02\x00\x00\x00" + b"\x01\x00\x00\x00\x07\x00\x00\x00" + b"\xc8\x03" +
+            b"\x00\x00\x00\x00" +
+            b"\x01\x00\x00\x00" + b"\x04\x00\x00\x00" + b"\xff")
+    assert wire.tobytes() == want
+    base = np.arange(9, dtype=np.uint8) + 100
+    shown, counts = po.wire_client(base, wire, 3)
+    assert counts.tolist() == [2, 0, 1]
+    assert shown[0].tolist() == [100, 45, 102, 103, 104, 105, 106, 110, 108]      # 101+200 wraps (opencv.cpp:65)
+    assert shown[1].tolist() == shown[0].tolist()
+    assert shown[2].tolist() == [100, 45, 102, 103, 103, 105, 106, 110, 108]
+    from cudavideostream_amd import synth
+    b, fr = synth.webcam_stream(6, 48, 20, seed=3)
+    o, x, d, st = po.diff_stream(fr, b)
+    shown, counts = po.wire_client(b, po.wire_pack(o, x, d), 6)
+    assert np.array_equal(shown[-1], st)
+    assert np.array_equal(counts, np.diff(o.astype(np.int64)))
+    assert (np.abs(shown.astype(np.int16) - fr.astype(np.int16)) <= 20).all()
