@@ -252,8 +252,47 @@ def host_path(args, base, frames, reps=60):
         dt = time.perf_counter() - t0 - copy_s
         for a in (h_frame, n_frame, o_frame, h_xs):
             a.free()
+        # the same frames with several in flight (mi355_pipe_*): upload of frame k+1 beside the kernels of
+        # frame k, no host synchronisation between the pack and the way back.  One pinned buffer set per
+        # resident frame, depth of them in flight.
+        depth, preps = 4, 4 * reps
+        from cudavideostream_amd.core import PinnedArray
+        nsrc = src.shape[0]
+        ring = [(PinnedArray(n + 32), PinnedArray(4 * n + 32, np.int32)) for _ in range(nsrc)]
+        for k in range(nsrc):
+            ring[k][0].array[:n] = src[k]
+        c.set_state(base.cpu().numpy())
+        c.pipe_open(depth)
+        tickets = [None] * nsrc
+        fill_s = 0.0
+
+        def finish(k):
+            # the diff bytes overwrote the head of the frame (in/out buffer, kernels.cu:461,522): put the
+            # frame back, which in the server is the capture thread's job
+            nonlocal fill_s
+            pos = c.exec_wait(tickets[k])
+            tickets[k] = None
+            tc = time.perf_counter()
+            ring[k][0].array[:pos] = src[k][:pos]
+            fill_s += time.perf_counter() - tc
+
+        t0 = time.perf_counter()
+        for i in range(preps):
+            if i >= depth:
+                finish((i - depth) % nsrc)
+            k = i % nsrc
+            tickets[k] = c.exec_submit(ring[k][0].array, None, "", ring[k][1].array)
+        for i in range(preps, preps + depth):
+            finish((i - depth) % nsrc)
+        dt_pipe = time.perf_counter() - t0 - fill_s
+        c.pipe_close()
+        for bufs in ring:
+            for a in bufs:
+                a.free()
     return {"frames_per_s": round(reps / dt, 1), "ms_per_frame": round(dt / reps * 1e3, 4),
-            "note": "mi355_exec per frame: H2D frame + kernels + D2H count/diff/xs, 2 syncs (PCIe-inclusive)"}
+            "note": "mi355_exec per frame: H2D frame + kernels + D2H count/diff/xs, 2 syncs (PCIe-inclusive)",
+            "pipelined_frames_per_s": round(preps / dt_pipe, 1), "pipeline_depth": depth,
+            "pcie_h2d_gbps": round(preps * n / dt_pipe / 1e9, 2)}
 
 
 def pair_mode(args, core, frames, d_off, d_xs, d_df, cap, n):

@@ -39,6 +39,15 @@ public:
                    int *h_xs);
     // kernels.cu:527-529
     size_t chunkt_size();
+
+    // ---- additions (not in the reference; non-virtual, the object layout is unchanged) -----------------
+    // exec_core split in two so that several frames are in flight (include/mi355diff.h, mi355_pipe_*):
+    // the elaboration thread of threads.cpp:134-147 submits frame k, then waits for frame k-1 and hands
+    // it to the sender, instead of blocking twice inside exec_core for every frame.
+    void pipe_open(int depth);
+    long long exec_submit(uint8_t *frameData, uint8_t *showReadyNData, std::string &text, int *h_xs);
+    void exec_wait(long long ticket, unsigned int *h_pos);
+    void pipe_close();
 };
 
 static_assert(sizeof(CUDACore) == 160, "must match the reference's object size (LP64)");

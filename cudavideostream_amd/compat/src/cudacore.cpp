@@ -70,6 +70,23 @@ void CUDACore::exec_core(uint8_t *frameData, uint8_t *showReadyNData, std::strin
     *h_pos = pos;
 }
 
+void CUDACore::pipe_open(int depth) { MI355_CHECK(mi355_pipe_open(core_, depth)); }
+
+void CUDACore::pipe_close() { MI355_CHECK(mi355_pipe_close(core_)); }
+
+long long CUDACore::exec_submit(uint8_t *frameData, uint8_t *showReadyNData, std::string &text, int *h_xs) {
+    int64_t ticket = -1;
+    MI355_CHECK(mi355_pipe_submit(core_, frameData, showReadyNData, text.empty() ? nullptr : text.c_str(),
+                                  reinterpret_cast<int32_t *>(h_xs), &ticket));
+    return ticket;
+}
+
+void CUDACore::exec_wait(long long ticket, unsigned int *h_pos) {
+    uint32_t pos = 0;
+    MI355_CHECK(mi355_pipe_wait(core_, ticket, &pos));
+    *h_pos = pos;
+}
+
 size_t CUDACore::chunkt_size() { return 32; }  // sizeof(long4), kernels.cu:27,527-529
 
 void CUDACore::alloc_arrays(uint8_t **h_frame, uint8_t **n_frame, uint8_t **o_frame, int **h_xs, int r,

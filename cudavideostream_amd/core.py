@@ -139,6 +139,27 @@ class CUDACore:
                                       C.addressof(pos), _ptr(h_xs)))
         return pos.value
 
+    # -- exec_core, pipelined (threads.cpp's ring moved below the boundary) ----------------------------
+    def pipe_open(self, depth=3):
+        _l.check(self._lib.mi355_pipe_open(self._h, int(depth)))
+
+    def pipe_close(self):
+        _l.check(self._lib.mi355_pipe_close(self._h))
+
+    def exec_submit(self, frame_data, show_ready_n_data, text, h_xs):
+        """Arguments of exec_core (pinned buffers); returns a ticket for exec_wait."""
+        ticket = C.c_int64(-1)
+        t = text.encode() if text else None
+        _l.check(self._lib.mi355_pipe_submit(self._h, _ptr(frame_data), _ptr(show_ready_n_data), t, _ptr(h_xs),
+                                             C.byref(ticket)))
+        return ticket.value
+
+    def exec_wait(self, ticket):
+        """Blocks until the frame's outputs are in its buffers; returns h_pos."""
+        pos = C.c_uint32(0)
+        _l.check(self._lib.mi355_pipe_wait(self._h, ticket, C.byref(pos)))
+        return pos.value
+
     # -- state ------------------------------------------------------------------------------------
     def set_state(self, frame):
         frame = np.ascontiguousarray(frame, dtype=np.uint8).reshape(-1)

@@ -70,6 +70,20 @@ struct mi355_core {
 
     uint32_t *h_count = nullptr;  // pinned, 2 x u32 (offsets[0..1] of exec)
 
+    // pipelined per-frame path (mi355_pipe_*): a ring of slots, uploads on their own stream
+    static constexpr int kMaxSlots = 8;
+    struct Slot {
+        uint8_t *d_in = nullptr, *d_vis = nullptr;
+        uint32_t *h_count = nullptr;                   // pinned, written by k_export
+        hipEvent_t uploaded = nullptr, painted = nullptr, packed = nullptr, shown = nullptr;
+        bool has_vis = false;
+        int64_t ticket = -1;                           // frame in flight in this slot, -1 = free
+    };
+    Slot slots[kMaxSlots];
+    int nslots = 0;
+    int64_t next_ticket = 0;
+    hipStream_t up_stream = nullptr, down_stream = nullptr;
+
     // timing: ring of event triplets {before pack, after pack, after gather}, harvested lazily so
     // that timed batches still queue back to back
     static constexpr int kEvRing = 32;
@@ -258,6 +272,7 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
 void mi355_destroy(mi355_core *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->nslots) (void)mi355_pipe_close(c);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->meta, c->segoff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
                     c->lut, c->glyphs};
@@ -524,15 +539,69 @@ int mi355_filter_batch(mi355_core *c, int op, const void *d_in, const void *d_in
 }
 
 // CUDACore::exec_core, kernels.cu:430-525.
+namespace {
+
+// kernels.cu:466-502: text overlay on the frame, then the visualisers that look at the frame before the
+// diff (heat / gray / binarize), or the canvas the red maps are painted on afterwards.
+int prepare_frame(mi355_core *c, uint8_t *frame, uint8_t *vis_out, const char *text, hipStream_t s) {
+    const int vis = c->cfg.visualizer;
+    const uint32_t N = c->n, npix = N / 3;
+    const FrameBatch one{N, 1};
+    if (text && c->glyphs) {
+        const size_t full_area = (size_t)3 * c->glyph_h * c->glyph_w;
+        int offset = 0;
+        for (const char *p = text; *p; ++p, offset += c->glyph_w * 3) {
+            const size_t idx = c->charset.find(*p);
+            if (idx == std::string::npos) continue;
+            HIP_TRY(launch_blit_glyph(frame, c->glyphs + idx * full_area, c->glyph_h, 3 * c->glyph_w, offset,
+                                      3 * c->cfg.width, c->cfg.height, s));
+        }
+    }
+    if (vis == MI355_VIS_HEAT) {
+        HIP_TRY(launch_heat_map(frame, c->state, vis_out, npix, c->lut, one, s));
+    } else if (vis == MI355_VIS_GRAY) {
+        HIP_TRY(launch_gray(frame, vis_out, npix, true, one, s));
+    } else if (vis == MI355_VIS_BINARIZE) {
+        // grayscale_kernel_v3 + histogram + compute_max + binarize (kernels.cu:493-498), fused: the
+        // gray frame is never materialised
+        HIP_TRY(launch_gray_binarize_fused(frame, vis_out, npix, true, c->hist, c->thr, one, s));
+    } else if (vis == MI355_VIS_RED_OVERLAP) {
+        // kernels.cu:517 paints onto d_previous, i.e. the state *before* this frame's feedback
+        HIP_TRY(hipMemcpyAsync(vis_out, c->state, N, hipMemcpyDeviceToDevice, s));
+    } else if (vis == MI355_VIS_RED) {
+        HIP_TRY(hipMemsetAsync(vis_out, 0, N, s));                      // kernels.cu:513
+    }
+    return MI355_OK;
+}
+
+int check_exec_args(mi355_core *c, const void *frame_data, const void *show_ready, const void *h_xs) {
+    if (!c || !frame_data || !h_xs) return fail(MI355_ERR_INVALID, "null argument");
+    if (c->cfg.visualizer != MI355_VIS_NONE && !show_ready)
+        return fail(MI355_ERR_INVALID, "visualizer set but show_ready is null");
+    if (c->cfg.noise_filter && !c->have_k9) return fail(MI355_ERR_STATE, "noise filter on but no conv kernel set");
+    return MI355_OK;
+}
+
+bool is_pinned(const void *p) {
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+}  // namespace
+
 int mi355_exec(mi355_core *c, uint8_t *frame_data, uint8_t *show_ready, const char *text,
                uint32_t *h_pos, int32_t *h_xs) {
-    if (!c || !frame_data || !h_pos || !h_xs) return fail(MI355_ERR_INVALID, "null argument");
+    if (!h_pos) return fail(MI355_ERR_INVALID, "null argument");
+    if (int rc = check_exec_args(c, frame_data, show_ready, h_xs)) return rc;
+    if (c->nslots) return fail(MI355_ERR_STATE, "pipe open: use mi355_pipe_submit");
     const int vis = c->cfg.visualizer;
-    if (vis != MI355_VIS_NONE && !show_ready) return fail(MI355_ERR_INVALID, "visualizer set but show_ready is null");
-    if (c->cfg.noise_filter && !c->have_k9) return fail(MI355_ERR_STATE, "noise filter on but no conv kernel set");
     if (int rc = use_device(c)) return rc;
     hipStream_t s = c->stream;
-    const uint32_t N = c->n, npix = N / 3;
+    const uint32_t N = c->n;
     const FrameBatch one{N, 1};
 
     // kernels.cu:457-462  H2D (+ convolution when NOISE_FILTER)
@@ -542,32 +611,7 @@ int mi355_exec(mi355_core *c, uint8_t *frame_data, uint8_t *show_ready, const ch
     } else {
         HIP_TRY(hipMemcpyAsync(c->in, frame_data, N, hipMemcpyHostToDevice, s));
     }
-    // kernels.cu:466-476  text overlay, one glyph per character
-    if (text && c->glyphs) {
-        const size_t full_area = (size_t)3 * c->glyph_h * c->glyph_w;
-        int offset = 0;
-        for (const char *p = text; *p; ++p, offset += c->glyph_w * 3) {
-            const size_t idx = c->charset.find(*p);
-            if (idx == std::string::npos) continue;
-            HIP_TRY(launch_blit_glyph(c->in, c->glyphs + idx * full_area, c->glyph_h, 3 * c->glyph_w, offset,
-                                      3 * c->cfg.width, c->cfg.height, s));
-        }
-    }
-    // kernels.cu:478-502  visualisers that look at the frame before the diff
-    if (vis == MI355_VIS_HEAT) {
-        HIP_TRY(launch_heat_map(c->in, c->state, c->vis, npix, c->lut, one, s));
-    } else if (vis == MI355_VIS_GRAY) {
-        HIP_TRY(launch_gray(c->in, c->vis, npix, true, one, s));
-    } else if (vis == MI355_VIS_BINARIZE) {
-        // grayscale_kernel_v3 + histogram + compute_max + binarize (kernels.cu:493-498), fused: the
-        // gray frame is never materialised
-        HIP_TRY(launch_gray_binarize_fused(c->in, c->vis, npix, true, c->hist, c->thr, one, s));
-    } else if (vis == MI355_VIS_RED_OVERLAP) {
-        // kernels.cu:517 paints onto d_previous, i.e. the state *before* this frame's feedback
-        HIP_TRY(hipMemcpyAsync(c->vis, c->state, N, hipMemcpyDeviceToDevice, s));
-    } else if (vis == MI355_VIS_RED) {
-        HIP_TRY(hipMemsetAsync(c->vis, 0, N, s));                      // kernels.cu:513
-    }
+    if (int rc = prepare_frame(c, c->in, c->vis, text, s)) return rc;
     if (vis == MI355_VIS_HEAT || vis == MI355_VIS_GRAY || vis == MI355_VIS_BINARIZE)
         HIP_TRY(hipMemcpyAsync(show_ready, c->vis, N, hipMemcpyDeviceToHost, s));
 
@@ -589,6 +633,118 @@ int mi355_exec(mi355_core *c, uint8_t *frame_data, uint8_t *show_ready, const ch
         HIP_TRY(hipMemcpyAsync(h_xs, c->one_xs, (size_t)pos * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(hipStreamSynchronize(s));
+    return MI355_OK;
+}
+
+// ---- pipelined per-frame path --------------------------------------------------------------------------
+int mi355_pipe_close(mi355_core *c) {
+    if (!c) return fail(MI355_ERR_INVALID, "null core");
+    if (int rc = use_device(c)) return rc;
+    if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
+    if (c->down_stream) (void)hipStreamSynchronize(c->down_stream);
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < c->nslots; i++) {
+        mi355_core::Slot &sl = c->slots[i];
+        if (sl.d_in) { (void)hipFree(sl.d_in); c->workspace -= c->n + 16; }
+        if (sl.d_vis) { (void)hipFree(sl.d_vis); c->workspace -= c->n + 16; }
+        if (sl.h_count) (void)hipHostFree(sl.h_count);
+        for (hipEvent_t e : {sl.uploaded, sl.painted, sl.packed, sl.shown}) if (e) (void)hipEventDestroy(e);
+        sl = mi355_core::Slot{};
+    }
+    c->nslots = 0;
+    if (c->up_stream) { (void)hipStreamDestroy(c->up_stream); c->up_stream = nullptr; }
+    if (c->down_stream) { (void)hipStreamDestroy(c->down_stream); c->down_stream = nullptr; }
+    return MI355_OK;
+}
+
+int mi355_pipe_open(mi355_core *c, int depth) {
+    if (!c) return fail(MI355_ERR_INVALID, "null core");
+    if (depth < 1 || depth > mi355_core::kMaxSlots) return fail(MI355_ERR_INVALID, "depth outside [1, 8]");
+    if (c->nslots) return fail(MI355_ERR_STATE, "pipe already open");
+    if (int rc = use_device(c)) return rc;
+    int rc = MI355_OK;
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking)) != hipSuccess) rc = fail(MI355_ERR_HIP, "hipStreamCreate", e);
+    if (!rc && (e = hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking)) != hipSuccess) rc = fail(MI355_ERR_HIP, "hipStreamCreate", e);
+    c->nslots = depth;   // so that a failed open is undone by pipe_close
+    const bool vis = c->cfg.visualizer != MI355_VIS_NONE;
+    for (int i = 0; i < depth && !rc; i++) {
+        mi355_core::Slot &sl = c->slots[i];
+        rc = dev_alloc(c, &sl.d_in, (size_t)c->n + 16);
+        if (!rc && vis) rc = dev_alloc(c, &sl.d_vis, (size_t)c->n + 16);
+        if (!rc && (e = hipHostMalloc((void **)&sl.h_count, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) rc = fail(MI355_ERR_HIP, "hipHostMalloc", e);
+        for (hipEvent_t *ev : {&sl.uploaded, &sl.painted, &sl.packed, &sl.shown})
+            if (!rc && (e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) rc = fail(MI355_ERR_HIP, "hipEventCreate", e);
+    }
+    if (rc) {
+        const std::string keep = g_err;
+        (void)mi355_pipe_close(c);
+        g_err = keep;
+        return rc;
+    }
+    c->next_ticket = 0;
+    return MI355_OK;
+}
+
+int mi355_pipe_submit(mi355_core *c, uint8_t *frame_data, uint8_t *show_ready, const char *text, int32_t *h_xs,
+                      int64_t *ticket) {
+    if (!ticket) return fail(MI355_ERR_INVALID, "null argument");
+    if (int rc = check_exec_args(c, frame_data, show_ready, h_xs)) return rc;
+    if (!c->nslots) return fail(MI355_ERR_STATE, "pipe not open");
+    if (int rc = use_device(c)) return rc;
+    // the kernels store through these pointers: pageable memory would fault on the device
+    if (!is_pinned(frame_data) || !is_pinned(h_xs) || (show_ready && !is_pinned(show_ready)))
+        return fail(MI355_ERR_INVALID, "pipe buffers must be pinned host memory (mi355_host_alloc)");
+    const int vis = c->cfg.visualizer;
+    const uint32_t N = c->n;
+    const FrameBatch one{N, 1};
+    mi355_core::Slot &sl = c->slots[c->next_ticket % c->nslots];
+    hipStream_t s = c->stream;
+    if (sl.ticket >= 0) {   // ring full: the slot's previous frame was never waited for; finish it first
+        HIP_TRY(hipEventSynchronize(sl.packed));
+        if (sl.has_vis) HIP_TRY(hipEventSynchronize(sl.shown));
+        sl.ticket = -1;
+    }
+    // upload on its own stream: frame k+1 crosses PCIe while frame k is packed (threads.cpp's capture and
+    // elaboration threads overlap the same way, threads.cpp:59-106,134-147)
+    HIP_TRY(hipMemcpyAsync(sl.d_in, frame_data, N, hipMemcpyHostToDevice, c->up_stream));
+    HIP_TRY(hipEventRecord(sl.uploaded, c->up_stream));
+    HIP_TRY(hipStreamWaitEvent(s, sl.uploaded, 0));
+    uint8_t *frame = sl.d_in;
+    if (c->cfg.noise_filter) {
+        HIP_TRY(launch_conv3x3(sl.d_in, c->in, c->cfg.width, c->cfg.height, c->k9, one, s));
+        frame = c->in;
+    }
+    if (int rc = prepare_frame(c, frame, sl.d_vis, text, s)) return rc;
+    if (int rc = run_batch(c, false, frame, nullptr, N, 1, c->offsets, c->one_xs, c->one_diff, N)) return rc;
+    if (vis == MI355_VIS_RED || vis == MI355_VIS_RED_OVERLAP)
+        HIP_TRY(launch_red_overlap(sl.d_vis, c->one_xs, c->offsets + 1, 0, N, s));
+    sl.has_vis = vis != MI355_VIS_NONE;
+    if (sl.has_vis) {   // the visualisation frame goes back on a third stream, beside the next frame's kernels
+        HIP_TRY(hipEventRecord(sl.painted, s));
+        HIP_TRY(hipStreamWaitEvent(c->down_stream, sl.painted, 0));
+        HIP_TRY(hipMemcpyAsync(show_ready, sl.d_vis, N, hipMemcpyDeviceToHost, c->down_stream));
+        HIP_TRY(hipEventRecord(sl.shown, c->down_stream));
+    }
+    // count, indices and differences leave through the mapped pointers: no host round trip for the count
+    HIP_TRY(launch_export(c->offsets, c->one_xs, c->one_diff, h_xs, frame_data, sl.h_count, s));
+    HIP_TRY(hipEventRecord(sl.packed, s));
+    sl.ticket = c->next_ticket;
+    *ticket = c->next_ticket++;
+    return MI355_OK;
+}
+
+int mi355_pipe_wait(mi355_core *c, int64_t ticket, uint32_t *h_pos) {
+    if (!c || !h_pos) return fail(MI355_ERR_INVALID, "null argument");
+    if (!c->nslots) return fail(MI355_ERR_STATE, "pipe not open");
+    if (ticket < 0 || ticket >= c->next_ticket) return fail(MI355_ERR_INVALID, "unknown ticket");
+    mi355_core::Slot &sl = c->slots[ticket % c->nslots];
+    if (sl.ticket != ticket) return fail(MI355_ERR_STATE, "ticket already waited for or overwritten");
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(hipEventSynchronize(sl.packed));
+    if (sl.has_vis) HIP_TRY(hipEventSynchronize(sl.shown));
+    *h_pos = *sl.h_count;
+    sl.ticket = -1;
     return MI355_OK;
 }
 

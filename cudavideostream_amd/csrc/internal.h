@@ -61,6 +61,8 @@ hipError_t launch_apply(uint8_t *frame, uint32_t nbytes, const void *xs, const v
                         const uint32_t *d_offsets, int t, uint32_t host_count, hipStream_t s);
 hipError_t launch_apply_all(uint8_t *frame, uint32_t nbytes, const int32_t *xs, const uint8_t *diff,
                             const uint32_t *d_offsets, int nframes, hipStream_t s);
+hipError_t launch_export(const uint32_t *offsets, const int32_t *xs, const uint8_t *diff, int32_t *h_xs,
+                         uint8_t *h_diff, uint32_t *h_count, hipStream_t s);
 hipError_t launch_merge(const MergeArgs &a, uint32_t *out_offsets, hipStream_t s);
 
 // filters.hip -- every per-frame kernel takes a FrameBatch: frame f lives at base + f*stride

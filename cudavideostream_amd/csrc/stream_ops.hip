@@ -78,6 +78,39 @@ hipError_t launch_apply_all(uint8_t *frame, uint32_t nbytes, const int32_t *xs, 
     return hipGetLastError();
 }
 
+// ---- export of one packed frame into host-mapped (pinned) buffers ---------------------------------------
+// The pipelined per-frame path has no host synchronisation between the pack and the copies back
+// (the reference reads the count, synchronises, then sizes two cudaMemcpy with it,
+// server/src/kernels.cu:507-524): the count stays on the device and this kernel stores exactly `count`
+// entries, and the count itself, through the PCIe-mapped pointers.
+__global__ __launch_bounds__(256) void k_export(const uint32_t *offsets, const int32_t *xs, const uint8_t *diff,
+                                                int32_t *h_xs, uint8_t *h_diff, uint32_t *h_count) {
+    const uint32_t count = offsets[1] - offsets[0];
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x, step = gridDim.x * 256u;
+    if (gid == 0) *h_count = count;
+    // 16-byte stores where the host pointers allow (the device arrays are allocation aligned)
+    if (((uintptr_t)h_xs & 15u) == 0) {
+        const uint32_t q = count / 4;
+        for (uint32_t i = gid; i < q; i += step) ((uint4 *)h_xs)[i] = ((const uint4 *)xs)[i];
+        for (uint32_t i = 4 * q + gid; i < count; i += step) h_xs[i] = xs[i];
+    } else {
+        for (uint32_t i = gid; i < count; i += step) h_xs[i] = xs[i];
+    }
+    if (((uintptr_t)h_diff & 15u) == 0) {
+        const uint32_t q = count / 16;
+        for (uint32_t i = gid; i < q; i += step) ((uint4 *)h_diff)[i] = ((const uint4 *)diff)[i];
+        for (uint32_t i = 16 * q + gid; i < count; i += step) h_diff[i] = diff[i];
+    } else {
+        for (uint32_t i = gid; i < count; i += step) h_diff[i] = diff[i];
+    }
+}
+
+hipError_t launch_export(const uint32_t *offsets, const int32_t *xs, const uint8_t *diff, int32_t *h_xs,
+                         uint8_t *h_diff, uint32_t *h_count, hipStream_t s) {
+    hipLaunchKernelGGL(k_export, dim3(256), dim3(256), 0, s, offsets, xs, diff, h_xs, h_diff, h_count);
+    return hipGetLastError();
+}
+
 // ---- merge of row-band streams -------------------------------------------------------------------------
 // Part p (a row band, bands ordered top to bottom) holds its own packed stream of the same T frames:
 // index part_off[p][0..T], entries at xs_all/diff_all[part_base[p] + ...], byte indices relative to

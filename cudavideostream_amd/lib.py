@@ -71,6 +71,11 @@ SYMBOLS = {
     "mi355_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi355_filter_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "mi355_exec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]),
+    "mi355_pipe_open": (C.c_int, [C.c_void_p, C.c_int]),
+    "mi355_pipe_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p,
+                                    C.POINTER(C.c_int64)]),
+    "mi355_pipe_wait": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_uint32)]),
+    "mi355_pipe_close": (C.c_int, [C.c_void_p]),
     "mi355_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "mi355_host_free": (C.c_int, [C.c_void_p]),
     "mi355_set_timing": (C.c_int, [C.c_void_p, C.c_int]),

@@ -185,6 +185,25 @@ int mi355_filter_batch(mi355_core *core, int op, const void *d_in, const void *d
 int mi355_exec(mi355_core *core, uint8_t *frame_data, uint8_t *show_ready, const char *text,
                uint32_t *h_pos, int32_t *h_xs);
 
+/* ---- the same entry point, pipelined ----------------------------------------------
+ * The reference overlaps capture, elaboration and sending with three threads around a ring of six pinned
+ * slots (server/src/threads.cpp:59-106,134-147,166-179) but exec_core itself blocks the host twice per
+ * frame (kernels.cu:508,524).  Here the overlap moves below the boundary: mi355_pipe_submit enqueues the
+ * upload of frame k on a copy stream, its kernels on the core's stream and its results' way back, and
+ * returns; while frame k is packed, frame k+1 crosses PCIe.  The changed-byte count never visits the host
+ * in between: a device kernel stores exactly count indices/differences, and the count, through the mapped
+ * pinned pointers.  mi355_pipe_wait(ticket) blocks until that frame's outputs are in the caller's
+ * buffers and returns h_pos.  Frames are processed in submission order (the state carries over).
+ *   - every host buffer must be pinned memory of mi355_host_alloc (alloc_arrays, kernels.cu:531-536) and
+ *     stay untouched between submit and wait; argument meaning as mi355_exec;
+ *   - depth (1..8) frames may be in flight; submitting into a full ring first completes the oldest frame;
+ *   - mi355_exec is refused while the pipe is open. */
+int mi355_pipe_open(mi355_core *core, int depth);
+int mi355_pipe_submit(mi355_core *core, uint8_t *frame_data, uint8_t *show_ready, const char *text,
+                      int32_t *h_xs, int64_t *ticket);
+int mi355_pipe_wait(mi355_core *core, int64_t ticket, uint32_t *h_pos);
+int mi355_pipe_close(mi355_core *core);
+
 /* ---- pinned host memory: CUDACore::alloc_arrays (kernels.cu:531-536) ---------------------------- */
 int mi355_host_alloc(void **out, size_t bytes);
 int mi355_host_free(void *p);
