@@ -290,7 +290,7 @@ def host_path(args, base, frames, reps=60):
             for a in bufs:
                 a.free()
     return {"frames_per_s": round(reps / dt, 1), "ms_per_frame": round(dt / reps * 1e3, 4),
-            "note": "mi355_exec per frame: H2D frame + kernels + D2H count/diff/xs, 2 syncs (PCIe-inclusive)",
+            "note": "mi355_exec per frame, blocking: H2D frame + kernels + count/diff/xs stored to the pinned buffers, 1 sync (PCIe-inclusive)",
             "pipelined_frames_per_s": round(preps / dt_pipe, 1), "pipeline_depth": depth,
             "pcie_h2d_gbps": round(preps * n / dt_pipe / 1e9, 2)}
 

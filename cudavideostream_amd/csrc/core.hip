@@ -617,7 +617,20 @@ int mi355_exec(mi355_core *c, uint8_t *frame_data, uint8_t *show_ready, const ch
 
     // kernels.cu:505  kernel2
     if (int rc = run_batch(c, false, c->in, nullptr, N, 1, c->offsets, c->one_xs, c->one_diff, N)) return rc;
-    // kernels.cu:507-508  count back + first synchronisation
+    if (is_pinned(frame_data) && is_pinned(h_xs)) {
+        // Pinned buffers (alloc_arrays): the count stays on the device, the red maps take it from there and
+        // k_export stores count/diff/xs through the mapped pointers -- one synchronisation instead of the
+        // reference's two (kernels.cu:508,524); what the caller sees on return is the same.
+        if (vis == MI355_VIS_RED || vis == MI355_VIS_RED_OVERLAP) {
+            HIP_TRY(launch_red_overlap(c->vis, c->one_xs, c->offsets + 1, 0, N, s));
+            HIP_TRY(hipMemcpyAsync(show_ready, c->vis, N, hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(launch_export(c->offsets, c->one_xs, c->one_diff, h_xs, frame_data, c->h_count, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        *h_pos = c->h_count[0];
+        return MI355_OK;
+    }
+    // pageable buffers: the reference's sequence, kernels.cu:507-508 count back + first synchronisation
     HIP_TRY(hipMemcpyAsync(c->h_count, c->offsets, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const uint32_t pos = c->h_count[1];

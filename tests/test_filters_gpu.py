@@ -185,6 +185,26 @@ def test_exec_core_all_visualizers(po, vis, noise_filter):
             a.free()
 
 
+@pytest.mark.parametrize("vis", [0, 2, 5])
+def test_exec_core_pageable_buffers(po, vis):
+    """Callers that did not use alloc_arrays: the copies back are sized on the host as in the reference
+    (kernels.cu:507-524) instead of stored through mapped pointers; same results."""
+    w, h, T = 96, 54, 3
+    base, frames = synth.webcam_stream(T, w, h, seed=80 + vis)
+    n = 3 * w * h
+    with CUDACore(w, h, sample_mat_data=base, visualizer=vis) as core:
+        frame, show, h_xs = np.zeros(n + 32, np.uint8), np.zeros(n + 32, np.uint8), np.zeros(n + 8, np.int32)
+        state = base
+        for t in range(T):
+            frame[:n] = frames[t]
+            pos = core.exec_core(frame, show, "", h_xs)
+            c, xs, df, state, want_show = oracle_exec(po, frames[t], state, vis, None, False, w, h)
+            assert pos == c and np.array_equal(h_xs[:pos], xs) and np.array_equal(frame[:pos], df)
+            if want_show is not None:
+                assert np.array_equal(show[:n], want_show)
+        assert np.array_equal(core.get_state(), state)
+
+
 def test_exec_core_text_overlay(po):
     """kernel2_char (kernels.cu:351-375): glyph rows are blitted into the frame before the diff."""
     w, h = 96, 54
