@@ -424,29 +424,19 @@ __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t v) {   // 0x80 per no
     return (((v & kL) + kL) | v) & kH;
 }
 
-__device__ __forceinline__ int kth_set_bit(uint64_t mask, uint32_t k) {
-    uint32_t w = (uint32_t)mask;
-    int base = 0;
-    const uint32_t c = (uint32_t)__builtin_popcount(w);
-    if (k >= c) { k -= c; w = (uint32_t)(mask >> 32); base = 32; }
-#pragma unroll
-    for (int sh = 16; sh > 0; sh >>= 1) {
-        const uint32_t low = w & ((1u << sh) - 1u);
-        const uint32_t cl = (uint32_t)__builtin_popcount(low);
-        if (k >= cl) { k -= cl; w >>= sh; base += sh; } else { w = low; }
-    }
-    return base;
-}
-
 #ifndef MI355_XTILES
 #define MI355_XTILES 64
 #endif
 constexpr uint32_t kXTiles = MI355_XTILES;   // tiles per workgroup (power of two, <= 64)
-constexpr int kXLog = kXTiles == 64 ? 6 : kXTiles == 32 ? 5 : kXTiles == 16 ? 4 : 3;
 #ifndef MI355_XROUNDS
 #define MI355_XROUNDS 3
 #endif
 constexpr int kXRounds = MI355_XROUNDS;   // rounds of 256 records per pass (even)
+#ifndef MI355_XLIGHT
+#define MI355_XLIGHT 4
+#endif
+constexpr uint32_t kXLight = MI355_XLIGHT;   // records with more flagged bytes than this are "heavy"
+constexpr int kXHeavyMax = 12;               // more heavy records than this in a wave: everybody walks
 constexpr uint32_t kXEntries = 3072;    // entries staged in LDS per workgroup; denser workgroups store directly
 
 // WIRE: the entries leave in the sender's byte stream instead (server/src/threads.cpp:227-229): frame t
@@ -457,11 +447,12 @@ __device__ __forceinline__ void store_u32_unaligned(uint8_t *p, uint32_t v) { __
 template <bool WIRE>
 __global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
     __shared__ uint64_t s_mask[kXTiles];
-    __shared__ uint32_t s_rincl[kXTiles];                 // inclusive prefix of records per tile
-    __shared__ uint32_t s_rpos[kXTiles];                  // log position of the tile's first record
+    __shared__ uint32_t s_rexcl[kXTiles];                 // records of the workgroup before this tile
+    __shared__ uint32_t s_rbase[kXTiles];                 // log position of the tile's first record - s_rexcl
+    __shared__ uint16_t s_src[kXTiles * 64];              // record r of the workgroup -> (tile << 6) | source lane
     __shared__ uint32_t s_wave[4][(kXRounds + 1) / 2];    // per wave: packed byte totals per round pair
-    __shared__ uint32_t s_total;                          // entries of this workgroup
-    __shared__ int32_t s_xs[kXEntries];
+    __shared__ uint32_t s_total, s_nrec;                  // entries / records of this workgroup
+    __shared__ uint16_t s_xs[kXEntries];                  // byte index relative to the workgroup's first tile
     __shared__ uint8_t s_df[kXEntries];
     const int t = blockIdx.y;
     const uint32_t tile0 = blockIdx.x * kXTiles;
@@ -488,42 +479,46 @@ __global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
         uint4 m = make_uint4(0, 0, 0, 0);
         if ((uint32_t)lane < kXTiles && tile < a.ntiles) m = a.meta[row + tile];
         const uint64_t mask = (uint64_t)m.x | ((uint64_t)m.y << 32);
-        const uint32_t rincl = (uint32_t)wave_inclusive_scan(__builtin_popcountll(mask));
+        const uint32_t nr = (uint32_t)__builtin_popcountll(mask);
+        const uint32_t rincl = (uint32_t)wave_inclusive_scan((int)nr);
         const uint32_t bytes = (uint32_t)wave_inclusive_scan((int)m.z);
         if ((uint32_t)lane < kXTiles) {
             s_mask[lane] = mask;
-            s_rpos[lane] = m.w;
-            s_rincl[lane] = rincl;
+            s_rexcl[lane] = rincl - nr;
+            s_rbase[lane] = m.w - (rincl - nr);
         }
-        if (lane == 63) s_total = bytes;
+        if (lane == 63) { s_total = bytes; s_nrec = rincl; }
     }
     __syncthreads();
-    const uint32_t nrec = s_rincl[kXTiles - 1];
+    const uint32_t nrec = s_nrec;
     if (nrec == 0) return;
     const uint32_t total = s_total;
     const bool staged = total <= kXEntries;
+    // where each record of the workgroup comes from: a wave walks its 16 tiles, candidate lanes write their
+    // (tile, lane) at the record's rank -- replaces a search per record
+#pragma unroll 4
+    for (uint32_t i = 0; i < kXTiles / 4; i++) {
+        const uint32_t sgm = (uint32_t)wave * (kXTiles / 4) + i;
+        const uint64_t mask = s_mask[sgm];
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if ((mask >> lane) & 1) s_src[s_rexcl[sgm] + rank] = (uint16_t)((sgm << 6) | (uint32_t)lane);
+    }
+    __syncthreads();
 
     uint32_t carry = 0;   // entries of earlier passes
     for (uint32_t base = 0; base < nrec; base += 256 * kXRounds) {
         uint4 rec[kXRounds];
-        uint32_t byte_base[kXRounds];
+        uint32_t src16[kXRounds];   // ((tile - tile0) << 6 | lane) * 16 = first byte of the record's lane, relative
 #pragma unroll
         for (int j = 0; j < kXRounds; j++) {
             rec[j] = make_uint4(0, 0, 0, 0);
-            byte_base[j] = 0;
+            src16[j] = 0;
             const uint32_t r = base + (uint32_t)j * 256u + threadIdx.x;   // round j: contiguous records
             if (r < nrec) {
-                uint32_t lo = 0, hi = kXTiles - 1;   // smallest sgm with s_rincl[sgm] > r
-#pragma unroll
-                for (int it = 0; it < kXLog; it++) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (s_rincl[mid] > r) hi = mid; else lo = mid + 1;
-                }
-                const uint32_t sgm = lo;
-                const uint32_t k = r - (sgm ? s_rincl[sgm - 1] : 0u);
-                const int src_lane = kth_set_bit(s_mask[sgm], k);
-                byte_base[j] = (tile0 + sgm) * kTileBytes + (uint32_t)src_lane * 16u;
-                rec[j] = a.rec[rec_index(s_rpos[sgm] + k, tile0 + sgm, a.ntiles)];
+                const uint32_t src = s_src[r];
+                const uint32_t sgm = src >> 6;
+                src16[j] = src * 16u;
+                rec[j] = a.rec[rec_index(r + s_rbase[sgm], tile0 + sgm, a.ntiles)];
             }
         }
         // 16-bit maps of the nonzero (= flagged) bytes: v_dot4 gathers the four 0x80 marks of a dword
@@ -559,39 +554,75 @@ __global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
             uint32_t e = run + before + ((incl[j / 2] >> sh) & 0xffffu) - cnt[j];   // index in the workgroup
             run += round_total;
             uint32_t m = m16[j];
-            while (m) {
-                const int b = __builtin_ctz(m);
-                m &= m - 1;
-                const uint32_t dw = b < 8 ? (b < 4 ? rec[j].x : rec[j].y) : (b < 12 ? rec[j].z : rec[j].w);
-                const int32_t xs = (int32_t)(byte_base[j] + (uint32_t)b);          // kernels.cu:315
-                const uint8_t df = (uint8_t)(dw >> (8 * (b & 3)));                  // kernels.cu:314
-                if (staged) {
-                    s_xs[e] = xs;
-                    s_df[e] = df;
-                } else if (WIRE) {
-                    if (w_room) {
-                        store_u32_unaligned(w_xs + 4 * (size_t)e, (uint32_t)xs);
-                        w_df[e] = df;
-                    }
-                } else if ((size_t)dst0 + e < a.capacity) {
-                    a.out_xs[dst0 + e] = xs;
-                    a.out_diff[dst0 + e] = df;
+            if (staged) {
+                // A lane walks the set bits of its record, so a wave pays for its densest record: a few
+                // records with many flagged bytes (the edges of a moving object among isolated bytes) are
+                // taken out of the walk and emitted one at a time by 16 lanes, one byte each.
+                const uint64_t heavy = __ballot(cnt[j] > kXLight);
+                const bool coop = __builtin_popcountll(heavy) <= kXHeavyMax;
+                const uint32_t e0 = e;
+                if (coop && cnt[j] > kXLight) m = 0;
+                while (m) {
+                    const int b = __builtin_ctz(m);
+                    m &= m - 1;
+                    const uint32_t dw = b < 8 ? (b < 4 ? rec[j].x : rec[j].y) : (b < 12 ? rec[j].z : rec[j].w);
+                    s_xs[e] = (uint16_t)(src16[j] + (uint32_t)b);                    // kernels.cu:315
+                    s_df[e] = (uint8_t)(dw >> (8 * (b & 3)));                        // kernels.cu:314
+                    ++e;
                 }
-                ++e;
+                if (coop) {
+                    const uint32_t b = (uint32_t)lane & 15u;
+                    for (uint64_t h = heavy; h; h &= h - 1) {
+                        const int hl = __builtin_ctzll(h);
+                        const uint32_t r0 = __builtin_amdgcn_readlane(rec[j].x, hl);
+                        const uint32_t r1 = __builtin_amdgcn_readlane(rec[j].y, hl);
+                        const uint32_t r2 = __builtin_amdgcn_readlane(rec[j].z, hl);
+                        const uint32_t r3 = __builtin_amdgcn_readlane(rec[j].w, hl);
+                        const uint32_t mm = __builtin_amdgcn_readlane(m16[j], hl);
+                        const uint32_t ee = __builtin_amdgcn_readlane(e0, hl);
+                        const uint32_t sb = __builtin_amdgcn_readlane(src16[j], hl);
+                        if (lane < 16 && ((mm >> b) & 1u)) {
+                            const uint32_t pos = ee + (uint32_t)__builtin_popcount(mm & ((1u << b) - 1u));
+                            const uint32_t dw = b < 8 ? (b < 4 ? r0 : r1) : (b < 12 ? r2 : r3);
+                            s_xs[pos] = (uint16_t)(sb + b);
+                            s_df[pos] = (uint8_t)(dw >> (8 * (b & 3)));
+                        }
+                    }
+                }
+            } else {
+                const uint32_t xs0 = tile0 * kTileBytes + src16[j];
+                while (m) {
+                    const int b = __builtin_ctz(m);
+                    m &= m - 1;
+                    const uint32_t dw = b < 8 ? (b < 4 ? rec[j].x : rec[j].y) : (b < 12 ? rec[j].z : rec[j].w);
+                    const uint8_t df = (uint8_t)(dw >> (8 * (b & 3)));
+                    if (WIRE) {
+                        if (w_room) {
+                            store_u32_unaligned(w_xs + 4 * (size_t)e, xs0 + (uint32_t)b);
+                            w_df[e] = df;
+                        }
+                    } else if ((size_t)dst0 + e < a.capacity) {
+                        a.out_xs[dst0 + e] = (int32_t)(xs0 + (uint32_t)b);
+                        a.out_diff[dst0 + e] = df;
+                    }
+                    ++e;
+                }
             }
         }
         carry = run;
         __syncthreads();   // s_wave is reused by the next pass; staged entries are complete after the last
     }
     if (staged) {
+        const uint32_t xs0 = tile0 * kTileBytes;
         for (uint32_t e = threadIdx.x; e < total; e += 256) {
+            const uint32_t xs = xs0 + s_xs[e];
             if (WIRE) {
                 if (w_room) {
-                    store_u32_unaligned(w_xs + 4 * (size_t)e, (uint32_t)s_xs[e]);
+                    store_u32_unaligned(w_xs + 4 * (size_t)e, xs);
                     w_df[e] = s_df[e];
                 }
             } else if ((size_t)dst0 + e < a.capacity) {
-                a.out_xs[dst0 + e] = s_xs[e];
+                a.out_xs[dst0 + e] = (int32_t)xs;
                 a.out_diff[dst0 + e] = s_df[e];
             }
         }
