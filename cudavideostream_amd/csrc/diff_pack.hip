@@ -109,7 +109,9 @@ __device__ __forceinline__ uint32_t bytes_sub_from_x(uint32_t a, uint32_t s, uin
 // v_perm selector: byte j picks byte j of the first operand where flagged, of the second otherwise
 __device__ __forceinline__ uint32_t perm_select(uint32_t fh) { return (fh >> 5) | 0x03020100u; }
 
-__device__ __forceinline__ uint4 load16_bytes(const uint8_t *p, int valid) {
+__device__ __forceinline__ uint4 load16_bytes(const uint8_t *p8, int valid) {
+    // global, not generic: a pointer rebuilt from scalar halves (uniform_ptr) has lost its address space
+    const __attribute__((address_space(1))) uint8_t *p = (const __attribute__((address_space(1))) uint8_t *)(uintptr_t)p8;
     uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 16; i++)
