@@ -41,6 +41,10 @@ def parse():
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--gather", choices=["every", "last", "index", "none"], default="last")
+    p.add_argument("--shard", choices=["streams", "roundrobin"], default="streams",
+                   help="streams: every rank owns an independent stateful stream (the headline workload); "
+                        "roundrobin: the frames of ONE sequence are dealt to the ranks and diffed against "
+                        "their raw predecessors, stateless (BASELINE config 5)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-pair", action="store_true")
@@ -128,7 +132,14 @@ def main():
 
     W, H, B, K = args.width, args.height, args.batch, args.steps
     n = 3 * W * H
-    base, frames = synth.webcam_stream(B, W, H, seed=21 + rank, device=dev)
+    rr = args.shard == "roundrobin"
+    if rr:   # local frame k is global frame rank + k*world; its predecessor travels with it
+        mine = gx.roundrobin_frames(rank, world, B * world)
+        base = synth.webcam_frame(-1, W, H, seed=21, device=dev)
+        frames = torch.stack([synth.webcam_frame(t, W, H, seed=21, device=dev) for t in mine])
+        prevs = torch.stack([synth.webcam_frame(t - 1, W, H, seed=21, device=dev) for t in mine])
+    else:
+        base, frames = synth.webcam_stream(B, W, H, seed=21 + rank, device=dev)
     cap = max(B * n // 8, 1 << 20)
     d_off = torch.zeros(B + 1, dtype=torch.int32, device=dev)
     d_xs = torch.empty(cap, dtype=torch.int32, device=dev)
@@ -139,7 +150,10 @@ def main():
     core.set_state(base.cpu().numpy())
 
     def step(last):
-        core.diff_stream_batch(frames, B, d_off, d_xs, d_df, cap)
+        if rr:
+            core.diff_pairs_batch(frames, prevs, B, d_off, d_xs, d_df, cap)
+        else:
+            core.diff_stream_batch(frames, B, d_off, d_xs, d_df, cap)
         if world > 1:
             if args.gather == "every" or (args.gather == "last" and last):
                 gx.gather_payload(d_off, d_xs, d_df, dst=0)
@@ -199,25 +213,31 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": f"{W}x{H} BGR24 S1 webcam stream, {B}-frame batches resident in HBM, "
-                                   f"stateful diff+threshold(20)+pack, ordered output",
+            "config": {"workload": (f"{W}x{H} BGR24 S1 webcam sequence dealt round-robin to the ranks, {B}-frame "
+                                    f"batches resident in HBM, stateless diff against the raw predecessor"
+                                    f"+threshold(20)+pack, ordered output" if rr else
+                                    f"{W}x{H} BGR24 S1 webcam stream, {B}-frame batches resident in HBM, "
+                                    f"stateful diff+threshold(20)+pack, ordered output"),
                        "frames_per_step": B, "changed_bytes_per_frame": round(p_total / B, 1),
-                       "parallelism": f"{world} independent streams" if world > 1 else "1 stream",
+                       "parallelism": (f"frames round-robin over {world} ranks" if rr else
+                                       f"{world} independent streams" if world > 1 else "1 stream"),
                        "gather": args.gather if world > 1 else "n/a"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic,
-                         "kernel": "mi355::k_diff_pack<false,true>",
+                         "kernel": "mi355::k_diff_pack<true,true>" if rr else "mi355::k_diff_pack<false,true>",
                          "kernel_ms": round(pack_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "read_gbps_2N": round(2.0 * n * B / (pack_ms * 1e-3) / 1e9, 1),
                          "all_kernels_ms": round(ms_total / max(launches, 1), 4)},
         }
-        if world == 1 and not args.no_pair:
+        if rr:
+            out["roofline"]["traffic"] = None   # the PMC summary is for the stream kernel
+        if world == 1 and not args.no_pair and not rr:
             out["pair_mode"] = pair_mode(args, core, frames, d_off, d_xs, d_df, cap, n)
         if world == 1 and not args.no_host_path:
             out["host_path"] = host_path(args, base, frames)
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and not rr:
             out["cpu_baseline"], out["parity"] = cpu_baseline(args, base, frames, dev)
         else:
             out["cpu_baseline"] = None

@@ -107,3 +107,24 @@ def gather_bands(offsets, xs, diff, band_first_byte, core=None, dst=0):
     core.merge_parts(index.contiguous(), part_base, xs_bias, xs_all, df_all, nframes, out_off, out_xs, out_df,
                      total)
     return out_off, out_xs[:total], out_df[:total]
+
+
+# ---- E1, round-robin: frames of ONE sequence dealt to the ranks (BASELINE config 5) ----------------------
+def roundrobin_frames(rank, world, nframes):
+    """Global frame numbers rank `rank` processes: t = rank, rank + world, ... (stateless pair mode: every
+    frame travels with its own predecessor, so the ranks do not depend on each other)."""
+    return list(range(rank, nframes, world))
+
+
+def roundrobin_order(index, nframes):
+    """index[world, B+1] (gather_index / gather_payload on the root, B = ceil(nframes / world) local frames,
+    ranks with fewer frames pad with empty ones) -> for every global frame t the pair
+    (first entry, last entry) of its segment inside the rank-major gathered arrays, in frame order."""
+    world = index.shape[0]
+    idx = index.to(torch.int64) & 0xFFFFFFFF
+    base = torch.cumsum(idx[:, -1], 0) - idx[:, -1]          # rank r's entries start here
+    out = []
+    for t in range(nframes):
+        r, k = t % world, t // world
+        out.append((int(base[r] + idx[r, k]), int(base[r] + idx[r, k + 1])))
+    return out

@@ -260,3 +260,101 @@ def test_long_batch_crosses_expand_table_blocks(po):
     frames[255:258] = frames[0]      # quiet frames around the first block boundary
     with CUDACore(w, h, max_batch=T) as core:
         check_stream(po, core, base, frames)
+
+
+def _density_frames(rng, base, T, plan):
+    """Frames whose flagged-byte density varies by region: plan = [(first_byte, last_byte, p)], every
+    selected byte moves by more than the threshold, the rest by at most 3."""
+    n = base.size
+    frames = np.empty((T, n), np.uint8)
+    for t in range(T):
+        f = (base.astype(np.int16) + rng.integers(-3, 4, n)).clip(0, 255)
+        for a, b, p in plan:
+            hit = np.flatnonzero(rng.random(b - a) < p) + a
+            f[hit] = (base[hit].astype(np.int16) + np.where(base[hit] < 128, 60, -60) + 5 * (t % 3))
+        frames[t] = f.astype(np.uint8)
+    return frames
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_mixed_density_regions_cover_every_expander_path(po, seed):
+    """k_expand stages a workgroup's entries in LDS when they fit (<= 3072 per 64 tiles), stores directly
+    otherwise, walks light records lane by lane and emits records with more than 4 flagged bytes
+    cooperatively unless a wave holds more than 12 of them: regions of 64 KiB with densities from one byte
+    per few records up to every byte put each combination, and the boundaries between them, in one batch."""
+    rng = np.random.default_rng(100 + seed)
+    w, h, T = 1024, 160, 6                     # 491 520 bytes = 480 tiles = 7.5 workgroups of 64 tiles
+    n = 3 * w * h
+    base = rng.integers(0, 256, n).astype(np.uint8)
+    grp = 64 * 1024
+    dens = [0.0005, 0.004, 0.02, 0.045, 0.05, 0.3, 1.0, 0.01]     # 0.045..0.05: around 3072 entries / group
+    plan = [(g * grp, min((g + 1) * grp, n), dens[(g + seed) % len(dens)]) for g in range((n + grp - 1) // grp)]
+    # a few fully flagged 16-byte lanes (heavy records) sprinkled into the light regions: 1..20 per wave
+    for g in range(len(plan)):
+        a = g * grp
+        for k in range(1 + 3 * g):
+            s = a + 16 * int(rng.integers(0, grp // 16 - 1))
+            if s + 16 <= n:
+                plan.append((s, s + 16, 1.0))
+    frames = _density_frames(rng, base, T, plan)
+    off, xs, df, st = po.diff_stream(frames, base)
+    with CUDACore(w, h, sample_mat_data=base, max_batch=T) as core:
+        g_off, g_xs, g_df, _ = run_stream(core, frames)
+        assert np.array_equal(g_off, off)
+        assert np.array_equal(g_xs, xs)
+        assert np.array_equal(g_df, df)
+        assert np.array_equal(core.get_state(), st)
+        # the same batch as the sender's byte stream (k_expand<WIRE>)
+        core.set_state(base)
+        want = po.wire_pack(off, xs, df)
+        d_off = torch.zeros(T + 1, dtype=torch.int32, device=DEV)
+        d_wire = torch.full((want.size + 32,), 0x5C, dtype=torch.uint8, device=DEV)
+        core.diff_stream_wire_batch(to_dev(frames), T, d_off, d_wire, want.size)
+        core.synchronize()
+        wire = d_wire.cpu().numpy()
+        assert np.array_equal(wire[:want.size], want) and (wire[want.size:] == 0x5C).all()
+
+
+@pytest.mark.parametrize("per_group", [3071, 3072, 3073, 4097])
+def test_staging_boundary_exact_entry_counts(po, per_group):
+    """Exactly 3071 / 3072 / 3073 / 4097 flagged bytes inside one 64-tile workgroup (the LDS staging holds
+    3072 entries), next to an empty and a full group."""
+    rng = np.random.default_rng(per_group)
+    w, h = 1024, 64                            # 196 608 bytes = 3 groups of 64 tiles
+    n = 3 * w * h
+    base = rng.integers(0, 200, n).astype(np.uint8)
+    frame = base.copy()
+    hit = np.sort(rng.choice(64 * 1024, per_group, replace=False)) + 64 * 1024      # group 1
+    frame[hit] += 50
+    frame[2 * 64 * 1024:] += 50                                                       # group 2: every byte
+    c, xs, df, st = po.diff_pack(frame, base)
+    assert c == per_group + 64 * 1024
+    with CUDACore(w, h, sample_mat_data=base, max_batch=1) as core:
+        g_off, g_xs, g_df, _ = run_stream(core, frame[None, :])
+        assert g_off.tolist() == [0, c]
+        assert np.array_equal(g_xs, xs) and np.array_equal(g_df, df)
+        assert np.array_equal(core.get_state(), st)
+
+
+@pytest.mark.parametrize("heavy", [0, 1, 11, 12, 13, 14, 40, 64])
+def test_heavy_record_count_per_wave(po, heavy):
+    """`heavy` fully flagged lanes among the first 64 records of a workgroup, isolated bytes elsewhere: the
+    cooperative emission takes over up to 12 heavy records per wave and hands back above."""
+    rng = np.random.default_rng(heavy)
+    w, h = 1024, 22                            # 67 584 bytes: one full group of 64 tiles + 2 tiles
+    n = 3 * w * h
+    base = rng.integers(0, 200, n).astype(np.uint8)
+    frame = base.copy()
+    lanes = rng.permutation(64)                # records 0..63 of the group = the 64 lanes of tile 0, all candidates
+    for i, l in enumerate(lanes):
+        if i < heavy:
+            frame[16 * l:16 * l + 16] += 40
+        else:
+            frame[16 * l + int(rng.integers(0, 16))] += 40
+    frame[5000::97] += 30
+    c, xs, df, st = po.diff_pack(frame, base)
+    with CUDACore(w, h, sample_mat_data=base, max_batch=1) as core:
+        g_off, g_xs, g_df, _ = run_stream(core, frame[None, :])
+        assert g_off.tolist() == [0, c]
+        assert np.array_equal(g_xs, xs) and np.array_equal(g_df, df)
+        assert np.array_equal(core.get_state(), st)

@@ -141,6 +141,65 @@ def test_row_bands_of_one_stream_gather_to_the_whole_frame_stream(world):
     assert np.array_equal(np.concatenate(m_df), df)
 
 
+def _rr_local(rank, world, T, w, h):
+    """Rank-local work of BASELINE config 5: frames t = rank (mod world) of one sequence against their raw
+    predecessors (pair mode), padded with empty frames to the common local batch length."""
+    from oracle import pyoracle as po
+    base, frames = synth.webcam_stream(T, w, h, seed=55)
+    seq = np.concatenate([base[None, :], frames])            # seq[t + 1] = frame t, seq[t] its predecessor
+    mine = gx.roundrobin_frames(rank, world, T)
+    B = (T + world - 1) // world
+    offs, xs, df = [0], [], []
+    for t in mine:
+        c, x, d, _ = po.diff_pack(seq[t + 1], seq[t])
+        offs.append(offs[-1] + c); xs.append(x); df.append(d)
+    while len(offs) < B + 1:
+        offs.append(offs[-1])
+    return (np.array(offs, np.uint32), np.concatenate(xs) if xs else np.empty(0, np.int32),
+            np.concatenate(df) if df else np.empty(0, np.uint8))
+
+
+def _rr_worker(rank, world, port, T, w, h, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        off, xs, df = _rr_local(rank, world, T, w, h)
+        t_off = torch.from_numpy(off.view(np.int32).copy())
+        t_xs = torch.from_numpy(np.append(xs, np.int32(0)))
+        t_df = torch.from_numpy(np.append(df, np.uint8(0)))
+        totals, xs_all, df_all, index = gx.gather_payload(t_off, t_xs, t_df, dst=0)
+        if rank == 0:
+            q.put((gx.roundrobin_order(index, T), xs_all.numpy().copy(), df_all.numpy().copy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,T", [(2, 7), (3, 7), (3, 2)])
+def test_round_robin_frames_of_one_sequence(world, T):
+    """BASELINE config 5 (frames dealt round-robin to the GPUs, gather to one rank): the root finds every
+    frame's segment in frame order, equal to the single-process oracle on the whole sequence."""
+    from oracle import pyoracle as po
+    w, h = 40, 12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rr_worker, args=(r, world, port, T, w, h, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    order, xs_all, df_all = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    base, frames = synth.webcam_stream(T, w, h, seed=55)
+    seq = np.concatenate([base[None, :], frames])
+    assert len(order) == T
+    for t, (a, b) in enumerate(order):
+        c, x, d, _ = po.diff_pack(seq[t + 1], seq[t])
+        assert b - a == c
+        assert np.array_equal(xs_all[a:b], x) and np.array_equal(df_all[a:b], d)
+
+
 def test_single_process_passthrough():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     dist.init_process_group("gloo", rank=0, world_size=1)
