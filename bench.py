@@ -155,13 +155,16 @@ def main():
         else:
             core.diff_stream_batch(frames, B, d_off, d_xs, d_df, cap)
         if world > 1:
-            if args.gather == "every" or (args.gather == "last" and last):
+            # the path itself has no collective (independent streams); the one exchange step is the gather
+            # of the changed-pixel stream to rank 0: of the final batch ("last", the default), of every
+            # batch ("every"), or the per-frame index every step and the payload at the end ("index")
+            if args.gather == "every" or (args.gather in ("last", "index") and last):
                 gx.gather_payload(d_off, d_xs, d_df, dst=0)
-            elif args.gather in ("index", "last"):
+            elif args.gather == "index":
                 gx.gather_index(d_off, dst=0)
 
     for i in range(args.warmup):
-        step(False)
+        step(i == args.warmup - 1)   # the last warm-up step also runs the exchange (RCCL sets up its peer channels on first use)
     torch.cuda.synchronize()
     core.set_timing(True)
     core.reset_timing()
