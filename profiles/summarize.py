@@ -55,6 +55,7 @@ if trace:
         "rocprofv3 --kernel-trace, per-kernel launch durations (bench.py --steps N --warmup 2)\n" + "\n".join(lines) + "\n")
 
 pmc = {}
+others = defaultdict(dict)   # every other mi355 kernel: raw counter averages per launch, uncorrected
 for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     p = find(sub, "*counter_collection.csv")
     if not p:
@@ -64,9 +65,11 @@ for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         if r.get("Counter_Name") == ctr:
             vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     for k, v in vals.items():
+        big = [x for x in v if x > 0.5 * max(v)]  # the 256-frame launches, not the tiny checker ones
         if "k_diff_pack" in k:
-            big = [x for x in v if x > 0.5 * max(v)]  # the 256-frame launches, not the tiny checker ones
             pmc[ctr] = {"kernel": k, "launches": len(big), "avg_raw_KiB": sum(big) / len(big)}
+        elif "mi355" in k:
+            others[k.split("(")[0]][ctr + "_avg_raw_KiB"] = sum(big) / len(big)
 if pmc:
     f_raw = pmc.get("FETCH_SIZE", {}).get("avg_raw_KiB")
     w_raw = pmc.get("WRITE_SIZE", {}).get("avg_raw_KiB")
@@ -75,6 +78,8 @@ if pmc:
                    "128-B request of a wide coalesced read stream, so read bytes = 2 x FETCH_SIZE "
                    "(MI355X_MICROARCH.md, HBM); WRITE_SIZE is exact for 16-B-per-lane stores and "
                    "uncalibrated for the narrow log stores of this kernel"}
+    if others:
+        out["other_kernels_raw"] = others
     if f_raw is not None:
         out["read_bytes_per_launch"] = 2 * f_raw * 1024
     if w_raw is not None:
