@@ -188,7 +188,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     ExpandArgs g{};
     g.rec = c->rec;
     g.meta = c->meta;
-    g.segoff = c->segoff;
+    g.groff = c->segoff;
     g.offsets = (const uint32_t *)d_offsets;
     g.ntiles = c->ntiles;
     g.out_xs = (int32_t *)d_xs;
@@ -247,7 +247,7 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (!rc) rc = dev_alloc(c, &c->vis, N + 16);
     if (!rc) rc = dev_alloc(c, &c->rec, T * W * 64);
     if (!rc) rc = dev_alloc(c, &c->meta, T * W);
-    if (!rc) rc = dev_alloc(c, &c->segoff, T * W);
+    if (!rc) rc = dev_alloc(c, &c->segoff, T * expand_groups(c->ntiles));
     if (!rc) rc = dev_alloc(c, &c->totals, T);
     if (!rc) rc = dev_alloc(c, &c->offsets, T + 1);
     if (!rc) rc = dev_alloc(c, &c->one_xs, N + 4);

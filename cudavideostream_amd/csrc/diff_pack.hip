@@ -369,25 +369,57 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *l
     return r;
 }
 
-// grid = T, block = 1024: segoff[t][*] = exclusive scan of the byte counts (meta.z), totals[t] = sum.
-__global__ __launch_bounds__(1024) void k_scan_tiles(const uint4 *meta, uint32_t *segoff,
-                                                     uint32_t *totals, uint32_t ntiles) {
-    __shared__ uint32_t lds[17];
+// A *group* is the kXTiles consecutive tiles one k_expand workgroup owns; the expander needs, per frame,
+// the bytes in the groups before its own and rebuilds everything finer from the meta words.
+constexpr uint32_t kXTiles = 64;          // = one wave of k_scan_groups per group
+constexpr uint32_t kScanChunk = 1024;     // groups scanned per pass of k_scan_groups
+
+// grid = T, block = 256: groff[t][g] = flagged bytes of frame t in the groups before g, totals[t] = all
+// of them.  A wave loads the 64 byte counts of a group with one coalesced instruction and reduces them
+// with DPP; the (at most kScanChunk) group sums are scanned in LDS.
+__global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t *groff, uint32_t *totals,
+                                                     uint32_t ntiles, uint32_t ngroups) {
+    static_assert(kXTiles == 64, "one wave reduces one group");
+    __shared__ uint32_t s_sum[kScanChunk];
+    __shared__ uint32_t s_scan[5];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t row = (size_t)blockIdx.x * ntiles;
-    const uint32_t per = (ntiles + 1023) / 1024;
-    const uint32_t i0 = threadIdx.x * per;
-    uint32_t sum = 0;
-    for (uint32_t i = 0; i < per; i++)
-        if (i0 + i < ntiles) sum += meta[row + i0 + i].z;
-    uint32_t total;
-    uint32_t acc = block_exclusive_scan<16>(sum, lds, total);
-    for (uint32_t i = 0; i < per; i++) {
-        if (i0 + i < ntiles) {
-            segoff[row + i0 + i] = acc;
-            acc += meta[row + i0 + i].z;
+    uint32_t *out = groff + (size_t)blockIdx.x * ngroups;
+    uint32_t carry = 0;
+    for (uint32_t g0 = 0; g0 < ngroups; g0 += kScanChunk) {
+        const uint32_t gn = min(kScanChunk, ngroups - g0);
+        for (uint32_t g = wave * 4; g < gn; g += 16) {   // four groups per wave and round: four loads in flight
+            uint32_t z[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t tile = (g0 + g + k) * kXTiles + lane;
+                z[k] = (g + k < gn && tile < ntiles) ? meta[row + tile].z : 0u;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t incl = (uint32_t)wave_inclusive_scan((int)z[k]);
+                if (lane == 63 && g + k < gn) s_sum[g + k] = incl;
+            }
         }
+        __syncthreads();
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            const uint32_t idx = threadIdx.x * 4 + i;
+            v[i] = idx < gn ? s_sum[idx] : 0u;
+            sum += v[i];
+        }
+        uint32_t total;
+        uint32_t acc = carry + block_exclusive_scan<4>(sum, s_scan, total);   // ends with a barrier
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            const uint32_t idx = threadIdx.x * 4 + i;
+            if (idx < gn) out[g0 + idx] = acc;
+            acc += v[i];
+        }
+        carry += total;
     }
-    if (threadIdx.x == 0) totals[blockIdx.x] = total;
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
 // grid = 1, block = 1024: offsets[0..T] = exclusive scan of totals[0..T).
@@ -406,9 +438,12 @@ __global__ __launch_bounds__(1024) void k_scan_frames(const uint32_t *totals, ui
     if (threadIdx.x == 0) offsets[nframes] = carry;
 }
 
-hipError_t launch_scan(const uint4 *meta, uint32_t *segoff, uint32_t *totals, uint32_t ntiles,
+uint32_t expand_groups(uint32_t ntiles) { return (ntiles + kXTiles - 1) / kXTiles; }
+
+hipError_t launch_scan(const uint4 *meta, uint32_t *groff, uint32_t *totals, uint32_t ntiles,
                        int nframes, uint32_t *offsets, hipStream_t s) {
-    hipLaunchKernelGGL(k_scan_tiles, dim3(nframes), dim3(1024), 0, s, meta, segoff, totals, ntiles);
+    hipLaunchKernelGGL(k_scan_groups, dim3(nframes), dim3(256), 0, s, meta, groff, totals, ntiles,
+                       expand_groups(ntiles));
     hipLaunchKernelGGL(k_scan_frames, dim3(1), dim3(1024), 0, s, totals, offsets, nframes);
     return hipGetLastError();
 }
@@ -426,10 +461,6 @@ __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t v) {   // 0x80 per no
     return (((v & kL) + kL) | v) & kH;
 }
 
-#ifndef MI355_XTILES
-#define MI355_XTILES 64
-#endif
-constexpr uint32_t kXTiles = MI355_XTILES;   // tiles per workgroup (power of two, <= 64)
 #ifndef MI355_XROUNDS
 #define MI355_XROUNDS 3
 #endif
@@ -462,7 +493,7 @@ __global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // issued first: needed only when the entries leave, so their latency hides behind everything else
     const uint32_t off_t = a.offsets[t];
-    const uint32_t dst0 = off_t + a.segoff[row + tile0];   // < 2^32: the batch total is below 2^32
+    const uint32_t dst0 = off_t + a.groff[(size_t)t * gridDim.x + blockIdx.x];   // < 2^32: the batch total is below 2^32
     uint8_t *w_xs = nullptr, *w_df = nullptr;   // WIRE: this workgroup's first index / payload byte
     size_t w_room = 0;                          // WIRE: entries of this workgroup that fit in a.capacity bytes
     if (WIRE) {

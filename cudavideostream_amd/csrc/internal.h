@@ -29,7 +29,7 @@ struct PackArgs {
 struct ExpandArgs {
     const uint4 *rec;
     const uint4 *meta;        // [T][W]
-    const uint32_t *segoff;   // [T][W]  exclusive scan of the byte counts over tiles, per frame
+    const uint32_t *groff;    // [T][G]  flagged bytes of the frame before each group of 64 tiles (G = ceil(W/64))
     const uint32_t *offsets;  // [T+1]   exclusive scan of the frame totals
     uint32_t ntiles;
     int32_t *out_xs;
@@ -40,7 +40,8 @@ struct ExpandArgs {
 
 // diff_pack.hip
 hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, hipStream_t s);
-hipError_t launch_scan(const uint4 *meta, uint32_t *segoff, uint32_t *totals, uint32_t ntiles,
+uint32_t expand_groups(uint32_t ntiles);
+hipError_t launch_scan(const uint4 *meta, uint32_t *groff, uint32_t *totals, uint32_t ntiles,
                        int nframes, uint32_t *offsets, hipStream_t s);
 hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s);
 
