@@ -8,7 +8,7 @@
 //   rec       T*W*64*16    record log written by k_diff_pack: 16 masked diff bytes per candidate lane
 //                          (worst case: every lane of every frame), chunk-interleaved over tiles
 //   meta      T*W*16       per (frame, tile): candidate ballot, flagged-byte count, log position
-//   segoff    T*W*4;  totals T*4;  offsets (T+1)*4
+//   groff     T*ceil(W/64)*4;  totals (T+1)*4 (+ticket);  offsets (T+1)*4
 //   one_xs N*4, one_diff N exec(): packed output of a single frame before the D2H copies
 //   hist T*256*4, thr T*4 (per frame of a filter batch), k9 9*4, heat LUT 766*3, glyph atlas
 #include <cmath>
@@ -55,7 +55,7 @@ struct mi355_core {
 
     uint8_t *state = nullptr, *in = nullptr, *aux = nullptr, *vis = nullptr;
     uint4 *rec = nullptr, *meta = nullptr;
-    uint32_t *segoff = nullptr, *totals = nullptr;
+    uint32_t *groff = nullptr, *totals = nullptr;
     uint32_t *offsets = nullptr;  // T+1, used by exec()
     int32_t *one_xs = nullptr;
     uint8_t *one_diff = nullptr;
@@ -183,12 +183,12 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     const bool aligned = (((uintptr_t)d_cur | (uintptr_t)d_prev | stride) & 15u) == 0;
     HIP_TRY(launch_diff_pack(a, pair, aligned, c->stream));
     if (tev) HIP_TRY(hipEventRecord(tev[1], c->stream));
-    HIP_TRY(launch_scan(c->meta, c->segoff, c->totals, c->ntiles, nframes, (uint32_t *)d_offsets,
-                        c->stream));
+    HIP_TRY(launch_scan(c->meta, c->groff, c->totals, c->ntiles, nframes, (uint32_t *)d_offsets,
+                        c->totals + c->cfg.max_batch, c->stream));
     ExpandArgs g{};
     g.rec = c->rec;
     g.meta = c->meta;
-    g.groff = c->segoff;
+    g.groff = c->groff;
     g.offsets = (const uint32_t *)d_offsets;
     g.ntiles = c->ntiles;
     g.out_xs = (int32_t *)d_xs;
@@ -247,8 +247,9 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (!rc) rc = dev_alloc(c, &c->vis, N + 16);
     if (!rc) rc = dev_alloc(c, &c->rec, T * W * 64);
     if (!rc) rc = dev_alloc(c, &c->meta, T * W);
-    if (!rc) rc = dev_alloc(c, &c->segoff, T * expand_groups(c->ntiles));
-    if (!rc) rc = dev_alloc(c, &c->totals, T);
+    if (!rc) rc = dev_alloc(c, &c->groff, T * expand_groups(c->ntiles));
+    if (!rc) rc = dev_alloc(c, &c->totals, T + 1);   // + the scan kernel's ticket counter
+    if (!rc) { e = hipMemset(c->totals, 0, (T + 1) * sizeof(uint32_t)); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipMemset", e); }
     if (!rc) rc = dev_alloc(c, &c->offsets, T + 1);
     if (!rc) rc = dev_alloc(c, &c->one_xs, N + 4);
     if (!rc) rc = dev_alloc(c, &c->one_diff, N + 16);
@@ -274,7 +275,7 @@ void mi355_destroy(mi355_core *c) {
     (void)hipSetDevice(c->device);
     if (c->nslots) (void)mi355_pipe_close(c);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->meta, c->segoff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
+    void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->meta, c->groff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
                     c->lut, c->glyphs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_count) (void)hipHostFree(c->h_count);

@@ -24,7 +24,8 @@
 //                 of a tile are appended to a chunk-interleaved log (consecutive frames fill whole
 //                 cache lines; all tiles' current chunks are neighbours in memory).  Per (frame, tile)
 //                 one 16-byte meta word keeps {candidate ballot, flagged-byte count, log position}.
-//   k_scan_*    : per frame exclusive scan of the byte counts over tiles, then scan of the frame totals.
+//   k_scan_groups: per frame, flagged bytes before every group of 64 tiles; its last workgroup scans the
+//               frame totals into offsets[0..T].
 //   k_expand    : one workgroup per (frame, 64 tiles): turns records into the caller's packed,
 //                 frame-major, ascending (xs, diff) arrays through an LDS stage and coalesced stores.
 // No inter-workgroup communication inside a launch, no spin waits, results independent of dispatch
@@ -377,8 +378,11 @@ constexpr uint32_t kScanChunk = 1024;     // groups scanned per pass of k_scan_g
 // grid = T, block = 256: groff[t][g] = flagged bytes of frame t in the groups before g, totals[t] = all
 // of them.  A wave loads the 64 byte counts of a group with one coalesced instruction and reduces them
 // with DPP; the (at most kScanChunk) group sums are scanned in LDS.
+// The workgroup that finishes last (ticket counter, reset for the next launch) also scans the frame totals
+// into offsets[0..T]: one launch and one dependent round trip less than a separate kernel.
 __global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t *groff, uint32_t *totals,
-                                                     uint32_t ntiles, uint32_t ngroups) {
+                                                     uint32_t ntiles, uint32_t ngroups, uint32_t *ticket,
+                                                     uint32_t *offsets) {
     static_assert(kXTiles == 64, "one wave reduces one group");
     __shared__ uint32_t s_sum[kScanChunk];
     __shared__ uint32_t s_scan[5];
@@ -419,32 +423,39 @@ __global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t
         }
         carry += total;
     }
-    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
-}
-
-// grid = 1, block = 1024: offsets[0..T] = exclusive scan of totals[0..T).
-__global__ __launch_bounds__(1024) void k_scan_frames(const uint32_t *totals, uint32_t *offsets,
-                                                      int nframes) {
-    __shared__ uint32_t lds[17];
-    uint32_t carry = 0;
-    for (int base = 0; base < nframes; base += 1024) {
-        const int t = base + (int)threadIdx.x;
-        const uint32_t v = t < nframes ? totals[t] : 0u;
+    // totals and the ticket are agent-scope atomics: the workgroups run on different XCDs, whose L2s are
+    // not coherent for plain accesses
+    __shared__ uint32_t s_is_last;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&totals[blockIdx.x], carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_is_last = mine == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_is_last) return;
+    const uint32_t nframes = gridDim.x;
+    carry = 0;
+    for (uint32_t base = 0; base < nframes; base += 256) {
+        const uint32_t t = base + threadIdx.x;
+        const uint32_t v = t < nframes
+            ? __hip_atomic_load(&totals[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         uint32_t total;
-        const uint32_t ex = block_exclusive_scan<16>(v, lds, total);
+        const uint32_t ex = block_exclusive_scan<4>(v, s_scan, total);
         if (t < nframes) offsets[t] = carry + ex;
         carry += total;
     }
-    if (threadIdx.x == 0) offsets[nframes] = carry;
+    if (threadIdx.x == 0) {
+        offsets[nframes] = carry;
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 uint32_t expand_groups(uint32_t ntiles) { return (ntiles + kXTiles - 1) / kXTiles; }
 
 hipError_t launch_scan(const uint4 *meta, uint32_t *groff, uint32_t *totals, uint32_t ntiles,
-                       int nframes, uint32_t *offsets, hipStream_t s) {
+                       int nframes, uint32_t *offsets, uint32_t *ticket, hipStream_t s) {
     hipLaunchKernelGGL(k_scan_groups, dim3(nframes), dim3(256), 0, s, meta, groff, totals, ntiles,
-                       expand_groups(ntiles));
-    hipLaunchKernelGGL(k_scan_frames, dim3(1), dim3(1024), 0, s, totals, offsets, nframes);
+                       expand_groups(ntiles), ticket, offsets);
     return hipGetLastError();
 }
 

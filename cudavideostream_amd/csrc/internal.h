@@ -42,7 +42,8 @@ struct ExpandArgs {
 hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, hipStream_t s);
 uint32_t expand_groups(uint32_t ntiles);
 hipError_t launch_scan(const uint4 *meta, uint32_t *groff, uint32_t *totals, uint32_t ntiles,
-                       int nframes, uint32_t *offsets, hipStream_t s);
+                       int nframes, uint32_t *offsets, uint32_t *ticket /* zero between launches */,
+                       hipStream_t s);
 hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s);
 
 // stream_ops.hip
