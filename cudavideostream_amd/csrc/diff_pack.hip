@@ -481,12 +481,150 @@ constexpr int kXRounds = MI355_XROUNDS;   // rounds of 256 records per pass (eve
 #endif
 constexpr uint32_t kXLight = MI355_XLIGHT;   // records with more flagged bytes than this are "heavy"
 constexpr int kXHeavyMax = 12;               // more heavy records than this in a wave: everybody walks
-constexpr uint32_t kXEntries = 3072;    // entries staged in LDS per workgroup; denser workgroups store directly
+constexpr uint32_t kXEntries = 4096;   // LDS staging: a sparse workgroup's whole output, or one round (256 records) of a dense one
 
 // WIRE: the entries leave in the sender's byte stream instead (server/src/threads.cpp:227-229): frame t
 // is {u32 n, i32 xs[n], u8 diff[n]} at byte 4t + 5*offsets[t] of a.wire, so index and payload sections
 // start at arbitrary byte addresses (gfx950 global stores need no alignment).
 __device__ __forceinline__ void store_u32_unaligned(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
+// Entries [first, first + count) of a workgroup, staged in LDS at s_xs/s_df[0..count), leave with coalesced
+// stores: one dword per index, and the differences as whole dwords too (byte stores only for the up to
+// three bytes before and after the dword-aligned body of the destination).
+template <bool WIRE>
+__device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint16_t *s_xs, const uint8_t *s_df,
+                                              uint32_t first, uint32_t count, uint32_t xs0, uint32_t dst0,
+                                              uint8_t *w_xs, uint8_t *w_df, size_t w_room) {
+    uint8_t *xsp, *dfp;
+    uint32_t n;
+    if (WIRE) {
+        n = w_room ? count : 0u;
+        xsp = w_xs + 4 * (size_t)first;
+        dfp = w_df + first;
+    } else {
+        const size_t d = (size_t)dst0 + first;      // entries beyond the capacity are dropped
+        n = d >= a.capacity ? 0u : (uint32_t)(a.capacity - d < count ? a.capacity - d : count);
+        xsp = (uint8_t *)(a.out_xs + d);
+        dfp = a.out_diff + d;
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += 256) store_u32_unaligned(xsp + 4 * (size_t)i, xs0 + s_xs[i]);
+    const uint32_t lead = (4u - (uint32_t)((uintptr_t)dfp & 3u)) & 3u;
+    const uint32_t head = lead < n ? lead : n;
+    const uint32_t body = (n - head) >> 2;
+    if (threadIdx.x < head) dfp[threadIdx.x] = s_df[threadIdx.x];
+    for (uint32_t k = threadIdx.x; k < body; k += 256) {
+        const uint8_t *q = s_df + head + 4 * k;
+        const uint32_t v = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+        *reinterpret_cast<uint32_t *>(dfp + head + 4 * (size_t)k) = v;
+    }
+    const uint32_t tail = head + 4 * body + threadIdx.x;
+    if (tail < n) dfp[tail] = s_df[tail];
+}
+
+// The records of a workgroup, ROUNDS x 256 per pass: all record loads of a pass are issued before any is
+// used.  Sparse workgroups (DENSE = false) stage their whole output in LDS and flush it at the end;
+// dense ones stage and flush one round at a time.
+template <bool WIRE, int ROUNDS, bool DENSE>
+__device__ __forceinline__ void expand_records(const ExpandArgs &a, uint32_t nrec, uint32_t tile0, uint32_t dst0,
+                                               const uint16_t *s_src, const uint32_t *s_rbase, uint32_t *s_wave,
+                                               uint16_t *s_xs, uint8_t *s_df, uint8_t *w_xs, uint8_t *w_df,
+                                               size_t w_room) {
+    static_assert(ROUNDS <= 4, "s_wave holds two packed words per wave");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;   // entries of earlier passes
+    for (uint32_t base = 0; base < nrec; base += 256 * ROUNDS) {
+        uint4 rec[ROUNDS];
+        uint32_t src16[ROUNDS];   // ((tile - tile0) << 6 | lane) * 16 = first byte of the record's lane, relative
+#pragma unroll
+        for (int j = 0; j < ROUNDS; j++) {
+            rec[j] = make_uint4(0, 0, 0, 0);
+            src16[j] = 0;
+            const uint32_t r = base + (uint32_t)j * 256u + threadIdx.x;   // round j: contiguous records
+            if (r < nrec) {
+                const uint32_t src = s_src[r];
+                const uint32_t sgm = src >> 6;
+                src16[j] = src * 16u;
+                rec[j] = a.rec[rec_index(r + s_rbase[sgm], tile0 + sgm, a.ntiles)];
+            }
+        }
+        // 16-bit maps of the nonzero (= flagged) bytes: v_dot4 gathers the four 0x80 marks of a dword
+        // into 4 adjacent bits
+        uint32_t m16[ROUNDS], cnt[ROUNDS], incl[(ROUNDS + 1) / 2];
+#pragma unroll
+        for (int j = 0; j < ROUNDS; j++) {
+            const uint32_t g0 = __builtin_amdgcn_udot4(nonzero_bytes(rec[j].x), 0x08040201u, 0u, false);
+            const uint32_t g1 = __builtin_amdgcn_udot4(nonzero_bytes(rec[j].y), 0x08040201u, 0u, false);
+            const uint32_t g2 = __builtin_amdgcn_udot4(nonzero_bytes(rec[j].z), 0x08040201u, 0u, false);
+            const uint32_t g3 = __builtin_amdgcn_udot4(nonzero_bytes(rec[j].w), 0x08040201u, 0u, false);
+            m16[j] = (g0 + (g1 << 4) + (g2 << 8) + (g3 << 12)) >> 7;
+            cnt[j] = (uint32_t)__builtin_popcount(m16[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < (ROUNDS + 1) / 2; j++) {      // a round total is at most 256*16 = 4096
+            const uint32_t hi = 2 * j + 1 < ROUNDS ? cnt[(2 * j + 1) % ROUNDS] : 0u;
+            incl[j] = (uint32_t)wave_inclusive_scan((int)(cnt[2 * j] | (hi << 16)));
+            if (lane == 63) s_wave[wave * 2 + j] = incl[j];
+        }
+        __syncthreads();
+        uint32_t run = carry;   // entries before round j (all waves), then before this wave in round j
+#pragma unroll
+        for (int j = 0; j < ROUNDS; j++) {
+            const int sh = (j & 1) * 16;
+            uint32_t before = 0, round_total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const uint32_t v = (s_wave[w * 2 + j / 2] >> sh) & 0xffffu;
+                if (w < wave) before += v;
+                round_total += v;
+            }
+            const uint32_t round_first = run;   // entries of the workgroup before this round
+            // index in the LDS stage: within the workgroup (sparse) or within the round (dense)
+            uint32_t e = (DENSE ? 0u : run) + before + ((incl[j / 2] >> sh) & 0xffffu) - cnt[j];
+            run += round_total;
+            uint32_t m = m16[j];
+            // A lane walks the set bits of its record, so a wave pays for its densest record: a few
+            // records with many flagged bytes (the edges of a moving object among isolated bytes) are
+            // taken out of the walk and emitted one at a time by 16 lanes, one byte each.
+            const uint64_t heavy = __ballot(cnt[j] > kXLight);
+            const bool coop = __builtin_popcountll(heavy) <= kXHeavyMax;
+            const uint32_t e0 = e;
+            if (coop && cnt[j] > kXLight) m = 0;
+            while (m) {
+                const int b = __builtin_ctz(m);
+                m &= m - 1;
+                const uint32_t dw = b < 8 ? (b < 4 ? rec[j].x : rec[j].y) : (b < 12 ? rec[j].z : rec[j].w);
+                s_xs[e] = (uint16_t)(src16[j] + (uint32_t)b);                    // kernels.cu:315
+                s_df[e] = (uint8_t)(dw >> (8 * (b & 3)));                        // kernels.cu:314
+                ++e;
+            }
+            if (coop) {
+                const uint32_t b = (uint32_t)lane & 15u;
+                for (uint64_t h = heavy; h; h &= h - 1) {
+                    const int hl = __builtin_ctzll(h);
+                    const uint32_t r0 = __builtin_amdgcn_readlane(rec[j].x, hl);
+                    const uint32_t r1 = __builtin_amdgcn_readlane(rec[j].y, hl);
+                    const uint32_t r2 = __builtin_amdgcn_readlane(rec[j].z, hl);
+                    const uint32_t r3 = __builtin_amdgcn_readlane(rec[j].w, hl);
+                    const uint32_t mm = __builtin_amdgcn_readlane(m16[j], hl);
+                    const uint32_t ee = __builtin_amdgcn_readlane(e0, hl);
+                    const uint32_t sb = __builtin_amdgcn_readlane(src16[j], hl);
+                    if (lane < 16 && ((mm >> b) & 1u)) {
+                        const uint32_t pos = ee + (uint32_t)__builtin_popcount(mm & ((1u << b) - 1u));
+                        const uint32_t dw = b < 8 ? (b < 4 ? r0 : r1) : (b < 12 ? r2 : r3);
+                        s_xs[pos] = (uint16_t)(sb + b);
+                        s_df[pos] = (uint8_t)(dw >> (8 * (b & 3)));
+                    }
+                }
+            }
+            if (DENSE) {   // the round leaves now
+                __syncthreads();
+                flush_entries<WIRE>(a, s_xs, s_df, round_first, round_total, tile0 * kTileBytes, dst0, w_xs, w_df, w_room);
+            }
+        }
+        carry = run;
+        __syncthreads();   // s_wave is reused by the next pass; staged entries are complete after the last
+    }
+}
 
 template <bool WIRE>
 __global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
@@ -494,7 +632,7 @@ __global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
     __shared__ uint32_t s_rexcl[kXTiles];                 // records of the workgroup before this tile
     __shared__ uint32_t s_rbase[kXTiles];                 // log position of the tile's first record - s_rexcl
     __shared__ uint16_t s_src[kXTiles * 64];              // record r of the workgroup -> (tile << 6) | source lane
-    __shared__ uint32_t s_wave[4][(kXRounds + 1) / 2];    // per wave: packed byte totals per round pair
+    __shared__ uint32_t s_wave[4 * 2];                    // per wave: packed byte totals per round pair
     __shared__ uint32_t s_total, s_nrec;                  // entries / records of this workgroup
     __shared__ uint16_t s_xs[kXEntries];                  // byte index relative to the workgroup's first tile
     __shared__ uint8_t s_df[kXEntries];
@@ -549,127 +687,11 @@ __global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
     }
     __syncthreads();
 
-    uint32_t carry = 0;   // entries of earlier passes
-    for (uint32_t base = 0; base < nrec; base += 256 * kXRounds) {
-        uint4 rec[kXRounds];
-        uint32_t src16[kXRounds];   // ((tile - tile0) << 6 | lane) * 16 = first byte of the record's lane, relative
-#pragma unroll
-        for (int j = 0; j < kXRounds; j++) {
-            rec[j] = make_uint4(0, 0, 0, 0);
-            src16[j] = 0;
-            const uint32_t r = base + (uint32_t)j * 256u + threadIdx.x;   // round j: contiguous records
-            if (r < nrec) {
-                const uint32_t src = s_src[r];
-                const uint32_t sgm = src >> 6;
-                src16[j] = src * 16u;
-                rec[j] = a.rec[rec_index(r + s_rbase[sgm], tile0 + sgm, a.ntiles)];
-            }
-        }
-        // 16-bit maps of the nonzero (= flagged) bytes: v_dot4 gathers the four 0x80 marks of a dword
-        // into 4 adjacent bits
-        uint32_t m16[kXRounds], cnt[kXRounds], incl[(kXRounds + 1) / 2];
-#pragma unroll
-        for (int j = 0; j < kXRounds; j++) {
-            const uint32_t g0 = __builtin_amdgcn_udot4(nonzero_bytes(rec[j].x), 0x08040201u, 0u, false);
-            const uint32_t g1 = __builtin_amdgcn_udot4(nonzero_bytes(rec[j].y), 0x08040201u, 0u, false);
-            const uint32_t g2 = __builtin_amdgcn_udot4(nonzero_bytes(rec[j].z), 0x08040201u, 0u, false);
-            const uint32_t g3 = __builtin_amdgcn_udot4(nonzero_bytes(rec[j].w), 0x08040201u, 0u, false);
-            m16[j] = (g0 + (g1 << 4) + (g2 << 8) + (g3 << 12)) >> 7;
-            cnt[j] = (uint32_t)__builtin_popcount(m16[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < (kXRounds + 1) / 2; j++) {      // a round total is at most 256*16 = 4096
-            const uint32_t hi = 2 * j + 1 < kXRounds ? cnt[(2 * j + 1) % kXRounds] : 0u;
-            incl[j] = (uint32_t)wave_inclusive_scan((int)(cnt[2 * j] | (hi << 16)));
-            if (lane == 63) s_wave[wave][j] = incl[j];
-        }
-        __syncthreads();
-        uint32_t run = carry;   // entries before round j (all waves), then before this wave in round j
-#pragma unroll
-        for (int j = 0; j < kXRounds; j++) {
-            const int sh = (j & 1) * 16;
-            uint32_t before = 0, round_total = 0;
-#pragma unroll
-            for (int w = 0; w < 4; w++) {
-                const uint32_t v = (s_wave[w][j / 2] >> sh) & 0xffffu;
-                if (w < wave) before += v;
-                round_total += v;
-            }
-            uint32_t e = run + before + ((incl[j / 2] >> sh) & 0xffffu) - cnt[j];   // index in the workgroup
-            run += round_total;
-            uint32_t m = m16[j];
-            if (staged) {
-                // A lane walks the set bits of its record, so a wave pays for its densest record: a few
-                // records with many flagged bytes (the edges of a moving object among isolated bytes) are
-                // taken out of the walk and emitted one at a time by 16 lanes, one byte each.
-                const uint64_t heavy = __ballot(cnt[j] > kXLight);
-                const bool coop = __builtin_popcountll(heavy) <= kXHeavyMax;
-                const uint32_t e0 = e;
-                if (coop && cnt[j] > kXLight) m = 0;
-                while (m) {
-                    const int b = __builtin_ctz(m);
-                    m &= m - 1;
-                    const uint32_t dw = b < 8 ? (b < 4 ? rec[j].x : rec[j].y) : (b < 12 ? rec[j].z : rec[j].w);
-                    s_xs[e] = (uint16_t)(src16[j] + (uint32_t)b);                    // kernels.cu:315
-                    s_df[e] = (uint8_t)(dw >> (8 * (b & 3)));                        // kernels.cu:314
-                    ++e;
-                }
-                if (coop) {
-                    const uint32_t b = (uint32_t)lane & 15u;
-                    for (uint64_t h = heavy; h; h &= h - 1) {
-                        const int hl = __builtin_ctzll(h);
-                        const uint32_t r0 = __builtin_amdgcn_readlane(rec[j].x, hl);
-                        const uint32_t r1 = __builtin_amdgcn_readlane(rec[j].y, hl);
-                        const uint32_t r2 = __builtin_amdgcn_readlane(rec[j].z, hl);
-                        const uint32_t r3 = __builtin_amdgcn_readlane(rec[j].w, hl);
-                        const uint32_t mm = __builtin_amdgcn_readlane(m16[j], hl);
-                        const uint32_t ee = __builtin_amdgcn_readlane(e0, hl);
-                        const uint32_t sb = __builtin_amdgcn_readlane(src16[j], hl);
-                        if (lane < 16 && ((mm >> b) & 1u)) {
-                            const uint32_t pos = ee + (uint32_t)__builtin_popcount(mm & ((1u << b) - 1u));
-                            const uint32_t dw = b < 8 ? (b < 4 ? r0 : r1) : (b < 12 ? r2 : r3);
-                            s_xs[pos] = (uint16_t)(sb + b);
-                            s_df[pos] = (uint8_t)(dw >> (8 * (b & 3)));
-                        }
-                    }
-                }
-            } else {
-                const uint32_t xs0 = tile0 * kTileBytes + src16[j];
-                while (m) {
-                    const int b = __builtin_ctz(m);
-                    m &= m - 1;
-                    const uint32_t dw = b < 8 ? (b < 4 ? rec[j].x : rec[j].y) : (b < 12 ? rec[j].z : rec[j].w);
-                    const uint8_t df = (uint8_t)(dw >> (8 * (b & 3)));
-                    if (WIRE) {
-                        if (w_room) {
-                            store_u32_unaligned(w_xs + 4 * (size_t)e, xs0 + (uint32_t)b);
-                            w_df[e] = df;
-                        }
-                    } else if ((size_t)dst0 + e < a.capacity) {
-                        a.out_xs[dst0 + e] = (int32_t)(xs0 + (uint32_t)b);
-                        a.out_diff[dst0 + e] = df;
-                    }
-                    ++e;
-                }
-            }
-        }
-        carry = run;
-        __syncthreads();   // s_wave is reused by the next pass; staged entries are complete after the last
-    }
     if (staged) {
-        const uint32_t xs0 = tile0 * kTileBytes;
-        for (uint32_t e = threadIdx.x; e < total; e += 256) {
-            const uint32_t xs = xs0 + s_xs[e];
-            if (WIRE) {
-                if (w_room) {
-                    store_u32_unaligned(w_xs + 4 * (size_t)e, xs);
-                    w_df[e] = s_df[e];
-                }
-            } else if ((size_t)dst0 + e < a.capacity) {
-                a.out_xs[dst0 + e] = (int32_t)xs;
-                a.out_diff[dst0 + e] = s_df[e];
-            }
-        }
+        expand_records<WIRE, kXRounds, false>(a, nrec, tile0, dst0, s_src, s_rbase, s_wave, s_xs, s_df, w_xs, w_df, w_room);
+        flush_entries<WIRE>(a, s_xs, s_df, 0u, total, tile0 * kTileBytes, dst0, w_xs, w_df, w_room);
+    } else {
+        expand_records<WIRE, 1, true>(a, nrec, tile0, dst0, s_src, s_rbase, s_wave, s_xs, s_df, w_xs, w_df, w_room);
     }
 }
 
