@@ -28,8 +28,8 @@
 //               frame totals into offsets[0..T].
 //   k_expand    : one workgroup per (frame, 64 tiles): turns records into the caller's packed,
 //                 frame-major, ascending (xs, diff) arrays through an LDS stage and coalesced stores.
-// No inter-workgroup communication inside a launch, no spin waits, results independent of dispatch
-// order.
+// No spin waits; the only inter-workgroup communication is the completion ticket of k_scan_groups;
+// results are independent of dispatch order.
 #include "internal.h"
 
 namespace mi355 {
