@@ -774,6 +774,40 @@ int mi355_host_free(void *p) {
     return MI355_OK;
 }
 
+int mi355_dev_alloc(mi355_core *c, void **out, size_t bytes) {
+    if (!c || !out) return fail(MI355_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 16));
+    return MI355_OK;
+}
+
+int mi355_dev_free(mi355_core *c, void *d_ptr) {
+    if (!c) return fail(MI355_ERR_INVALID, "null core");
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));   // nothing of this core may still be using it
+    HIP_TRY(hipFree(d_ptr));
+    return MI355_OK;
+}
+
+int mi355_upload(mi355_core *c, void *d_dst, const void *host_src, size_t bytes) {
+    if (!c || (bytes && (!d_dst || !host_src))) return fail(MI355_ERR_INVALID, "null argument");
+    if (int rc = use_device(c)) return rc;
+    if (!bytes) return MI355_OK;
+    HIP_TRY(hipMemcpyAsync(d_dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MI355_OK;
+}
+
+int mi355_download(mi355_core *c, void *host_dst, const void *d_src, size_t bytes) {
+    if (!c || (bytes && (!host_dst || !d_src))) return fail(MI355_ERR_INVALID, "null argument");
+    if (int rc = use_device(c)) return rc;
+    if (!bytes) return MI355_OK;
+    HIP_TRY(hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MI355_OK;
+}
+
 int mi355_set_timing(mi355_core *c, int enabled) {
     if (!c) return fail(MI355_ERR_INVALID, "null core");
     if (int rc = use_device(c)) return rc;

@@ -78,6 +78,10 @@ SYMBOLS = {
     "mi355_pipe_close": (C.c_int, [C.c_void_p]),
     "mi355_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "mi355_host_free": (C.c_int, [C.c_void_p]),
+    "mi355_dev_alloc": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
+    "mi355_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi355_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi355_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi355_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "mi355_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int)]),

@@ -208,6 +208,16 @@ int mi355_pipe_close(mi355_core *core);
 int mi355_host_alloc(void **out, size_t bytes);
 int mi355_host_free(void *p);
 
+/* ---- device memory for hosts without a HIP binding ---------------------------------------------------
+ * The device-resident entry points take device pointers.  A caller that links the HIP runtime (or PyTorch)
+ * brings its own; a host language that reaches this library only through the C-ABI (cgo, JNI, ctypes ...)
+ * uses these: plain hipMalloc/hipFree on the core's device, and copies ordered on the core's stream
+ * (mi355_upload returns once the host buffer may be reused, mi355_download once the bytes are there). */
+int mi355_dev_alloc(mi355_core *core, void **out, size_t bytes);
+int mi355_dev_free(mi355_core *core, void *d_ptr);
+int mi355_upload(mi355_core *core, void *d_dst, const void *host_src, size_t bytes);
+int mi355_download(mi355_core *core, void *host_dst, const void *d_src, size_t bytes);
+
 /* ---- measurement ---------------------------------------------------------------------------------
  * With timing on, every *_batch call brackets its kernels with HIP events on the stream they are
  * launched on.  mi355_get_timing synchronises the stream and returns the sums since the last reset:

@@ -39,3 +39,20 @@ def test_stream_counts_match_oracle(po):
     base, frames = synth.webcam_stream(B, w, h, seed=21)
     off, _, _, _ = po.diff_stream(frames, base)
     assert abs(r["changed_bytes_per_frame"] * B - int(off[-1])) < 0.5 * B
+
+
+RT = os.path.join(ROOT, "tools", "roundtrip")
+
+
+@pytest.mark.skipif(not os.path.exists(RT), reason="tools/roundtrip not built")
+@pytest.mark.parametrize("w,h,T,B", [(320, 180, 24, 8), (97, 13, 10, 4), (1920, 1080, 6, 3)])
+def test_cpp_server_to_client_round_trip_over_the_c_abi(w, h, T, B):
+    """tools/roundtrip: a g++-only program (no HIP header) drives a server core and a client core through
+    include/mi355diff.h, moving the sender's byte stream through a pipe; it exits non-zero on any mismatch."""
+    out = subprocess.run([RT, "--width", str(w), "--height", str(h), "--frames", str(T), "--batch", str(B)],
+                         capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["roundtrip"] == "ok" and r["max_abs_error"] <= 20
+    assert r["wire_bytes"] == 4 * T + 5 * r["changed_bytes"]
+    assert r["wire_bytes"] < r["raw_bytes"]
