@@ -65,7 +65,7 @@ struct mi355_core {
     uint8_t *glyphs = nullptr;
     int nglyphs = 0, glyph_h = 0, glyph_w = 0;
     std::string charset;
-    bool have_k9 = false;
+    bool have_k9 = false, k9_sym = false;   // k9_sym: corners equal and edges equal, bit for bit
     size_t workspace = 0;
 
     uint32_t *h_count = nullptr;  // pinned, 2 x u32 (offsets[0..1] of exec)
@@ -334,6 +334,9 @@ int mi355_set_conv_kernel(mi355_core *c, const float *k9) {
     HIP_TRY(hipMemcpyAsync(c->k9, k9, 9 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_k9 = true;
+    uint32_t b[9];
+    memcpy(b, k9, sizeof b);
+    c->k9_sym = b[0] == b[2] && b[0] == b[6] && b[0] == b[8] && b[1] == b[3] && b[1] == b[5] && b[1] == b[7];
     return MI355_OK;
 }
 
@@ -503,7 +506,7 @@ int mi355_conv3x3(mi355_core *c, const void *d_in, void *d_out) {
     if (!c->have_k9) return fail(MI355_ERR_STATE, "mi355_set_conv_kernel not called");
     if (int rc = use_device(c)) return rc;
     HIP_TRY(launch_conv3x3((const uint8_t *)d_in, (uint8_t *)d_out, c->cfg.width, c->cfg.height, c->k9,
-                           FrameBatch{c->n, 1}, c->stream));
+                           c->k9_sym, FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
 }
 
@@ -533,7 +536,7 @@ int mi355_filter_batch(mi355_core *c, int op, const void *d_in, const void *d_in
             HIP_TRY(launch_gray_binarize_fused(in, out, npix, true, c->hist, c->thr, fb, c->stream)); break;
         case MI355_OP_HEAT_MAP: HIP_TRY(launch_heat_map(in, in2, out, npix, c->lut, fb, c->stream)); break;
         case MI355_OP_RED_DENSE: HIP_TRY(launch_red_dense(in, in2, out, npix, c->cfg.threshold, fb, c->stream)); break;
-        case MI355_OP_CONV3X3: HIP_TRY(launch_conv3x3(in, out, c->cfg.width, c->cfg.height, c->k9, fb, c->stream)); break;
+        case MI355_OP_CONV3X3: HIP_TRY(launch_conv3x3(in, out, c->cfg.width, c->cfg.height, c->k9, c->k9_sym, fb, c->stream)); break;
         default: return fail(MI355_ERR_INVALID, "unknown filter op");
     }
     return MI355_OK;
@@ -608,7 +611,7 @@ int mi355_exec(mi355_core *c, uint8_t *frame_data, uint8_t *show_ready, const ch
     // kernels.cu:457-462  H2D (+ convolution when NOISE_FILTER)
     if (c->cfg.noise_filter) {
         HIP_TRY(hipMemcpyAsync(c->aux, frame_data, N, hipMemcpyHostToDevice, s));
-        HIP_TRY(launch_conv3x3(c->aux, c->in, c->cfg.width, c->cfg.height, c->k9, one, s));
+        HIP_TRY(launch_conv3x3(c->aux, c->in, c->cfg.width, c->cfg.height, c->k9, c->k9_sym, one, s));
     } else {
         HIP_TRY(hipMemcpyAsync(c->in, frame_data, N, hipMemcpyHostToDevice, s));
     }
@@ -726,7 +729,7 @@ int mi355_pipe_submit(mi355_core *c, uint8_t *frame_data, uint8_t *show_ready, c
     HIP_TRY(hipStreamWaitEvent(s, sl.uploaded, 0));
     uint8_t *frame = sl.d_in;
     if (c->cfg.noise_filter) {
-        HIP_TRY(launch_conv3x3(sl.d_in, c->in, c->cfg.width, c->cfg.height, c->k9, one, s));
+        HIP_TRY(launch_conv3x3(sl.d_in, c->in, c->cfg.width, c->cfg.height, c->k9, c->k9_sym, one, s));
         frame = c->in;
     }
     if (int rc = prepare_frame(c, frame, sl.d_vis, text, s)) return rc;

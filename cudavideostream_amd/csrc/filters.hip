@@ -459,71 +459,142 @@ hipError_t launch_red_overlap(uint8_t *img, const int32_t *xs, const uint32_t *d
 // accumulator, taps in i-major / j-minor order, one multiply then one add per tap.
 // On the interleaved byte image this is a 2-D filter with a horizontal tap spacing of 3 bytes.
 //
-// k_conv3x3_rows (rows 16-byte aligned, i.e. 3*w % 16 == 0 -- 1080p and 4K): a workgroup produces
-// 4 rows x 1024 bytes; the 6 input rows x (1024 + 2*16) bytes are staged in LDS with 16-byte loads and
-// every lane computes 16 consecutive output bytes from three aligned 48-byte LDS windows per row
-// (66 byte->float conversions, 144 multiplies + 144 adds, 16 float->byte conversions: the kernel is
-// VALU-bound, not HBM-bound).  k_conv3x3_any is the byte-wise form for every other geometry.
-constexpr int kConvCols = 1024;   // output bytes per tile row (64 lanes x 16 B)
-constexpr int kConvRowsV = 4;     // output rows per workgroup
-
 __device__ __forceinline__ float byte_f(uint32_t dw, int b) {  // b is a compile-time constant
     return (float)((dw >> (8 * b)) & 0xffu);                   // v_cvt_f32_ubyteN
 }
 
-__global__ __launch_bounds__(256) void k_conv3x3_rows(const uint8_t *in, uint8_t *out, int rowbytes, int h,
-                                                      const float *k9, size_t stride) {
-    __shared__ uint4 tile[kConvRowsV + 2][kConvCols / 16 + 2];
+// k_conv3x3_strip (rows 16-byte aligned, i.e. 3*w % 16 == 0 -- 1080p and 4K; k_conv3x3_any is the byte-wise
+// form for every other geometry): a lane owns a column strip of 16 bytes x kStripRows rows and walks it
+// top to bottom.  An input row is converted once (22 floats: 16 bytes + 3 either side, the
+// neighbours' bytes re-read through the cache) and serves three output rows: as the bottom row of r-1
+// (taps k6..k8, after which r-1 is complete and stored), the middle row of r (k3..k5) and the top row of
+// r+1 (k0..k2) -- for every output the nine multiply-then-add steps happen in the reference's i-major,
+// j-minor order.  No LDS, no barriers.  SYM: k0=k2=k6=k8 and k1=k3=k5=k7 bit for bit (the reference's
+// Gaussian, server.cpp:20-36): a product k*in is the same float wherever it is used, so 76 products per
+// row serve the 144 tap positions.  The kernel is VALU-bound (tools/ubench/valu_rate.hip: on gfx950 a
+// byte<->float conversion costs a wave as much as two multiplies, and packed fp32 instructions issue at
+// half the rate of plain ones, i.e. no faster per element): ~13 instructions per output byte (SYM), ~15
+// (general), against 18 for the LDS-tiled row kernel it replaced (4.24 -> 3.53 us per 1080p frame).
+#ifndef MI355_CONV_STRIP
+#define MI355_CONV_STRIP 30
+#endif
+constexpr int kStripRows = MI355_CONV_STRIP;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef MI355_CONV_WAVES
+#define MI355_CONV_WAVES 2
+#endif
+#ifndef MI355_CONV_PAIRS
+#define MI355_CONV_PAIRS 8
+#endif
+constexpr int kConvPairs = MI355_CONV_PAIRS;   // output pairs per lane: 8 = 16-byte strips, 4 = 8-byte strips
+
+template <bool SYM, int NP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MI355_CONV_WAVES, MI355_CONV_WAVES)))
+void k_conv3x3_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, const float *k9, size_t stride) {
+    constexpr int LB = 2 * NP;      // bytes per lane and row
+    constexpr int NW = NP / 2;      // dwords per lane and row
     in += (size_t)blockIdx.z * stride;
     out += (size_t)blockIdx.z * stride;
-    const int xb0 = blockIdx.x * kConvCols, y0 = blockIdx.y * kConvRowsV;
+    const int xb = (blockIdx.x * 64 + threadIdx.x) * LB;
+    if (xb >= rowbytes) return;
+    const int y0 = blockIdx.y * kStripRows;
+    const int y1 = min(y0 + kStripRows, h);
     float kk[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) kk[i] = k9[i];
-    // stage: chunk (ry, cx) holds image bytes [xb0 - 16 + 16*cx, +16) of row y0 - 1 + ry
-    constexpr int kChunks = kConvCols / 16 + 2;
-    for (int i = threadIdx.x; i < (kConvRowsV + 2) * kChunks; i += 256) {
-        const int ry = i / kChunks, cx = i - ry * kChunks;
-        const int gy = y0 - 1 + ry, gx = xb0 - 16 + 16 * cx;
-        uint4 v = make_uint4(0, 0, 0, 0);                          // zero halo, kernels.cu:111-115
-        if (gy >= 0 && gy < h && gx >= 0 && gx < rowbytes)         // rowbytes % 16 == 0: whole chunks
-            v = *reinterpret_cast<const uint4 *>(in + (size_t)gy * rowbytes + gx);
-        tile[ry][cx] = v;
-    }
-    __syncthreads();
-    const int r = threadIdx.x >> 6, c = threadIdx.x & 63;
-    const int gy = y0 + r, gx = xb0 + 16 * c;
-    if (gy >= h || gx >= rowbytes) return;
-    float acc[16];
-#pragma unroll
-    for (int b = 0; b < 16; b++) acc[b] = 0.0f;                    // kernels.cu:120-122
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        // window = bytes [16c - 16, 16c + 32) of input row r + i (tile chunks c, c+1, c+2)
-        const uint4 a = tile[r + i][c], m = tile[r + i][c + 1], z = tile[r + i][c + 2];
-        // f[n] = byte (16c - 3 + n), n = 0..21
-        float f[22];
-        f[0] = byte_f(a.w, 1); f[1] = byte_f(a.w, 2); f[2] = byte_f(a.w, 3);
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            f[3 + b] = byte_f(m.x, b); f[7 + b] = byte_f(m.y, b);
-            f[11 + b] = byte_f(m.z, b); f[15 + b] = byte_f(m.w, b);
+    const bool has_l = xb > 0, has_r = xb + LB < rowbytes;
+
+    // Loads are unconditional (row and halo addresses clamped into the frame, the values zeroed afterwards):
+    // a load behind a branch makes the compiler wait for every outstanding load (s_waitcnt vmcnt(0)), i.e.
+    // the next row could not be in flight while this one is computed.
+    struct Row { uint32_t m[NW]; uint32_t l, r; };
+    auto load_row = [&](int r) {
+        const bool inside = r >= 0 && r < h;                        // zero outside the image, kernels.cu:111-115
+        const uint8_t *p = in + (size_t)min(max(r, 0), h - 1) * rowbytes + xb;
+        Row v;
+        if (NW == 4) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(p);
+            v.m[0] = t.x; v.m[1] = t.y; v.m[NW - 2] = t.z; v.m[NW - 1] = t.w;
+        } else {
+            const uint2 t = *reinterpret_cast<const uint2 *>(p);
+            v.m[0] = t.x; v.m[NW - 1] = t.y;
         }
-        f[19] = byte_f(z.x, 0); f[20] = byte_f(z.x, 1); f[21] = byte_f(z.x, 2);
+        v.l = *reinterpret_cast<const uint32_t *>(has_l ? p - 4 : p);
+        v.r = *reinterpret_cast<const uint32_t *>(has_r ? p + LB : p);
 #pragma unroll
-        for (int j = 0; j < 3; j++)
+        for (int d = 0; d < NW; d++)
+            if (!inside) v.m[d] = 0;
+        if (!inside || !has_l) v.l = 0;
+        if (!inside || !has_r) v.r = 0;
+        return v;
+    };
+    // One input row: B = accumulators of output row r-1, M = of row r, T = (fresh) of row r+1, as NP pairs
+    // of adjacent outputs (v_pk_mul_f32 / v_pk_add_f32 take even-aligned register pairs, so the pairing is
+    // spelled out).  With f[n] = byte xb - 3 + n, output pair q = outputs (2q, 2q+1) takes its left and right
+    // taps from e[q] = (f[2q], f[2q+1]) and e[q+3], and its middle tap from the centre bytes in their natural
+    // pairs c[q] = (f[2q+3], f[2q+4]): the centre bytes are needed in both pairings.
+    auto step = [&](int r, const Row &v, f32x2 (&B)[NP], f32x2 (&M)[NP], f32x2 (&T)[NP]) {
+        f32x2 e[NP + 3], c[NP];
+        e[0] = f32x2{byte_f(v.l, 1), byte_f(v.l, 2)};
+        e[1] = f32x2{byte_f(v.l, 3), byte_f(v.m[0], 0)};
 #pragma unroll
-            for (int b = 0; b < 16; b++) {
-                const float prod = kk[i * 3 + j] * f[b + 3 * j];   // kernels.cu:126-128: multiply ...
-                acc[b] = acc[b] + prod;                            // ... then add
+        for (int d = 0; d < NW; d++) {
+            c[2 * d] = f32x2{byte_f(v.m[d], 0), byte_f(v.m[d], 1)};
+            c[2 * d + 1] = f32x2{byte_f(v.m[d], 2), byte_f(v.m[d], 3)};
+            e[2 + 2 * d] = f32x2{byte_f(v.m[d], 1), byte_f(v.m[d], 2)};
+            e[3 + 2 * d] = f32x2{byte_f(v.m[d], 3), d + 1 < NW ? byte_f(v.m[d + 1 < NW ? d + 1 : d], 0) : byte_f(v.r, 0)};
+        }
+        e[NP + 2] = f32x2{byte_f(v.r, 1), byte_f(v.r, 2)};
+        if (SYM) {
+            f32x2 pc[NP + 3], pe[NP + 3];   // corner * e, edge * e
+#pragma unroll
+            for (int q = 0; q < 3; q++) { pc[q] = kk[0] * e[q]; pe[q] = kk[1] * e[q]; }
+#pragma unroll
+            for (int q = 0; q < NP; q++) {
+                pc[q + 3] = kk[0] * e[q + 3];
+                pe[q + 3] = kk[1] * e[q + 3];
+                const f32x2 po = kk[1] * c[q], pm = kk[4] * c[q];
+                B[q] = ((B[q] + pc[q]) + po) + pc[q + 3];             // k6 k7 k8
+                M[q] = ((M[q] + pe[q]) + pm) + pe[q + 3];             // k3 k4 k5
+                T[q] = (pc[q] + po) + pc[q + 3];                      // k0 k1 k2 (0 + p == p up to the sign of zero)
             }
-    }
-    uint32_t o[4];
+        } else {
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-        o[q] = ((uint32_t)acc[4 * q] & 0xffu) | (((uint32_t)acc[4 * q + 1] & 0xffu) << 8) |
-               (((uint32_t)acc[4 * q + 2] & 0xffu) << 16) | ((uint32_t)acc[4 * q + 3] << 24);   // :131-133
-    *reinterpret_cast<uint4 *>(out + (size_t)gy * rowbytes + gx) = make_uint4(o[0], o[1], o[2], o[3]);
+            for (int q = 0; q < NP; q++) {
+                B[q] = ((B[q] + kk[6] * e[q]) + kk[7] * c[q]) + kk[8] * e[q + 3];
+                M[q] = ((M[q] + kk[3] * e[q]) + kk[4] * c[q]) + kk[5] * e[q + 3];
+                T[q] = (kk[0] * e[q] + kk[1] * c[q]) + kk[2] * e[q + 3];
+            }
+        }
+        if (r - 1 >= y0) {   // output row r-1 is complete (r <= y1 here)
+            uint32_t o[NW];
+#pragma unroll
+            for (int d = 0; d < NW; d++)
+                o[d] = ((uint32_t)B[2 * d].x & 0xffu) | (((uint32_t)B[2 * d].y & 0xffu) << 8) |
+                       (((uint32_t)B[2 * d + 1].x & 0xffu) << 16) | ((uint32_t)B[2 * d + 1].y << 24);   // :131-133
+            uint8_t *dst = out + (size_t)(r - 1) * rowbytes + xb;
+            if (NW == 4) *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[NW - 2], o[NW - 1]);
+            else *reinterpret_cast<uint2 *>(dst) = make_uint2(o[0], o[NW - 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one row at a time: fewer products live at once
+    };
+
+    f32x2 a0[NP], a1[NP], a2[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) a0[q] = a1[q] = a2[q] = f32x2{0.0f, 0.0f};
+    Row cur = load_row(y0 - 1);
+    for (int r = y0 - 1; r <= y1; r += 3) {      // the three accumulator sets rotate through the roles
+        Row nxt = load_row(r + 1);
+        step(r, cur, a0, a1, a2);
+        if (r + 1 > y1) break;
+        cur = load_row(r + 2);
+        step(r + 1, nxt, a1, a2, a0);
+        if (r + 2 > y1) break;
+        nxt = load_row(r + 3);
+        step(r + 2, cur, a2, a0, a1);
+        cur = nxt;
+    }
 }
 
 constexpr int kConvTW = 64;    // output pixels per band (byte-wise kernel)
@@ -564,14 +635,16 @@ __global__ __launch_bounds__(256) void k_conv3x3_any(const uint8_t *in, uint8_t 
     }
 }
 
-hipError_t launch_conv3x3(const uint8_t *in, uint8_t *out, int w, int h, const float *k9, FrameBatch fb,
-                          hipStream_t s) {
+hipError_t launch_conv3x3(const uint8_t *in, uint8_t *out, int w, int h, const float *k9, bool k9_symmetric,
+                          FrameBatch fb, hipStream_t s) {
     if (w <= 0 || h <= 0 || fb.nframes <= 0) return hipSuccess;
     const int rowbytes = 3 * w;
     if (rowbytes % 16 == 0 && aligned16(in) && aligned16(out) && fb.stride % 16 == 0) {
-        const dim3 grid((rowbytes + kConvCols - 1) / kConvCols, (h + kConvRowsV - 1) / kConvRowsV,
-                        (unsigned)fb.nframes);
-        hipLaunchKernelGGL(k_conv3x3_rows, grid, dim3(256), 0, s, in, out, rowbytes, h, k9, fb.stride);
+        const dim3 grid((rowbytes / (2 * kConvPairs) + 63) / 64, (h + kStripRows - 1) / kStripRows, (unsigned)fb.nframes);
+        if (k9_symmetric)
+            hipLaunchKernelGGL((k_conv3x3_strip<true, kConvPairs>), grid, dim3(64), 0, s, in, out, rowbytes, h, k9, fb.stride);
+        else
+            hipLaunchKernelGGL((k_conv3x3_strip<false, kConvPairs>), grid, dim3(64), 0, s, in, out, rowbytes, h, k9, fb.stride);
     } else {
         const dim3 grid((w + kConvTW - 1) / kConvTW, (h + kConvRows - 1) / kConvRows, (unsigned)fb.nframes);
         hipLaunchKernelGGL(k_conv3x3_any, grid, dim3(256), 0, s, in, out, w, h, k9, fb.stride);

@@ -115,6 +115,24 @@ def test_conv3x3(po, w, h):
         assert np.array_equal(d_o.cpu().numpy(), po.conv3x3(img, w, h, kk))
 
 
+@pytest.mark.parametrize("w,h", [(16, 1), (16, 2), (16, 30), (16, 31), (32, 61), (352, 95), (3840, 66)])
+def test_conv3x3_column_strips(po, w, h):
+    """Geometries of k_conv3x3_strip (row bytes a multiple of 16): strips of 30 rows with 1..30 rows in the
+    last one, one to many 16-byte columns, with the symmetric (shared products) and the general form."""
+    rng = np.random.default_rng(w + 13 * h)
+    img = rng.integers(0, 256, 3 * w * h, dtype=np.uint8)
+    img[:3 * w] = 255                      # saturated first row against the zero padding
+    kernels = [po.gaussian_kernel(3, 1.5),
+               np.array([0.05, 0.1, 0.05, 0.1, 0.4, 0.1, 0.05, 0.1, 0.05], np.float32),      # symmetric
+               np.array([0.0625, 0.125, 0.0625, 0.125, 0.25, 0.125, 0.0625, 0.125, 0.0625], np.float32),
+               (lambda k: (k / k.sum()).astype(np.float32))(rng.random(9))]                 # general
+    for k in kernels:
+        with CUDACore(w, h, k=k) as core:
+            d_o = dev_out(img.size)
+            core.conv3x3(to_dev(img), d_o); core.synchronize()
+            assert np.array_equal(d_o.cpu().numpy(), po.conv3x3(img, w, h, k))
+
+
 def test_conv_requires_kernel_and_out_of_place():
     with CUDACore(8, 8) as core:
         d = dev_out(192)
