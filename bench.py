@@ -232,6 +232,9 @@ def main():
                          "kernel_ms": round(pack_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "read_gbps_2N": round(2.0 * n * B / (pack_ms * 1e-3) / 1e9, 1),
+                         # what the kernel really moves (PMC traffic / its duration): the state never leaves
+                         # the registers, so this is below the algorithmic figure
+                         "actual_gbps": round(traffic / (pack_ms * 1e-3) / 1e9, 1) if traffic else None,
                          "all_kernels_ms": round(ms_total / max(launches, 1), 4)},
         }
         if rr:
