@@ -245,6 +245,9 @@ class CUDACore:
     def conv3x3(self, d_in, d_out):
         _l.check(self._lib.mi355_conv3x3(self._h, _ptr(d_in), _ptr(d_out)))
 
+    def median5x5(self, d_in, d_out):
+        _l.check(self._lib.mi355_median5x5(self._h, _ptr(d_in), _ptr(d_out)))
+
     def filter_batch(self, op, d_in, d_out, nframes, d_in2=None, stride=None):
         """Batched per-frame filter (lib.OP_*): one launch per kernel for nframes frames."""
         stride = self.total if stride is None else stride

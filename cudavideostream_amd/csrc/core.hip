@@ -510,6 +510,15 @@ int mi355_conv3x3(mi355_core *c, const void *d_in, void *d_out) {
     return MI355_OK;
 }
 
+int mi355_median5x5(mi355_core *c, const void *d_in, void *d_out) {
+    if (!c || !d_in || !d_out) return fail(MI355_ERR_INVALID, "null argument");
+    if (d_in == d_out) return fail(MI355_ERR_INVALID, "median is not in-place");
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(launch_median5x5((const uint8_t *)d_in, (uint8_t *)d_out, c->cfg.width, c->cfg.height,
+                             FrameBatch{c->n, 1}, c->stream));
+    return MI355_OK;
+}
+
 int mi355_filter_batch(mi355_core *c, int op, const void *d_in, const void *d_in2, void *d_out,
                        size_t stride_bytes, int nframes) {
     if (!c) return fail(MI355_ERR_INVALID, "null core");
@@ -520,7 +529,8 @@ int mi355_filter_batch(mi355_core *c, int op, const void *d_in, const void *d_in
     const bool two = op == MI355_OP_HEAT_MAP || op == MI355_OP_RED_DENSE;
     if (two && !d_in2) return fail(MI355_ERR_INVALID, "this filter needs the previous frames (d_in2)");
     if (op == MI355_OP_CONV3X3 && !c->have_k9) return fail(MI355_ERR_STATE, "mi355_set_conv_kernel not called");
-    if (op == MI355_OP_CONV3X3 && d_in == d_out) return fail(MI355_ERR_INVALID, "conv3x3 cannot run in place");
+    if ((op == MI355_OP_CONV3X3 || op == MI355_OP_MEDIAN5X5) && d_in == d_out)
+        return fail(MI355_ERR_INVALID, "neighbourhood filters cannot run in place");
     if (int rc = use_device(c)) return rc;
     const uint8_t *in = (const uint8_t *)d_in, *in2 = (const uint8_t *)d_in2;
     uint8_t *out = (uint8_t *)d_out;
@@ -537,6 +547,7 @@ int mi355_filter_batch(mi355_core *c, int op, const void *d_in, const void *d_in
         case MI355_OP_HEAT_MAP: HIP_TRY(launch_heat_map(in, in2, out, npix, c->lut, fb, c->stream)); break;
         case MI355_OP_RED_DENSE: HIP_TRY(launch_red_dense(in, in2, out, npix, c->cfg.threshold, fb, c->stream)); break;
         case MI355_OP_CONV3X3: HIP_TRY(launch_conv3x3(in, out, c->cfg.width, c->cfg.height, c->k9, c->k9_sym, fb, c->stream)); break;
+        case MI355_OP_MEDIAN5X5: HIP_TRY(launch_median5x5(in, out, c->cfg.width, c->cfg.height, fb, c->stream)); break;
         default: return fail(MI355_ERR_INVALID, "unknown filter op");
     }
     return MI355_OK;

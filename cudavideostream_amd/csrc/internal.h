@@ -88,6 +88,7 @@ hipError_t launch_red_overlap(uint8_t *img, const int32_t *xs, const uint32_t *d
                               uint32_t count, uint32_t nbytes, hipStream_t s);
 hipError_t launch_conv3x3(const uint8_t *in, uint8_t *out, int w, int h, const float *k9, bool k9_symmetric,
                           FrameBatch fb, hipStream_t s);
+hipError_t launch_median5x5(const uint8_t *in, uint8_t *out, int w, int h, FrameBatch fb, hipStream_t s);
 hipError_t launch_blit_glyph(uint8_t *frame, const uint8_t *glyph, int glyph_h, int glyph_wbytes,
                              int x_off_bytes, int frame_wbytes, int frame_h, hipStream_t s);
 

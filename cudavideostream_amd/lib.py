@@ -18,7 +18,7 @@ ERR_STATE = -3
 
 VIS_NONE, VIS_HEAT, VIS_RED, VIS_RED_OVERLAP, VIS_GRAY, VIS_BINARIZE = range(6)
 (OP_GRAY_AVG, OP_GRAY_WEIGHTED, OP_BINARIZE, OP_GRAY_AVG_BINARIZE, OP_GRAY_WEIGHTED_BINARIZE, OP_HEAT_MAP,
- OP_RED_DENSE, OP_CONV3X3) = range(1, 9)
+ OP_RED_DENSE, OP_CONV3X3, OP_MEDIAN5X5) = range(1, 10)
 
 
 class Config(C.Structure):
@@ -69,6 +69,7 @@ SYMBOLS = {
     "mi355_red_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi355_red_overlap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "mi355_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355_median5x5": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi355_filter_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "mi355_exec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p]),
     "mi355_pipe_open": (C.c_int, [C.c_void_p, C.c_int]),

@@ -160,6 +160,10 @@ int mi355_red_overlap(mi355_core *core, void *d_img, const void *d_xs, const voi
 /* kernels.cu:97-136: 3x3 convolution with the kernel of mi355_set_conv_kernel; not in-place. */
 int mi355_conv3x3(mi355_core *core, const void *d_in, void *d_out);
 
+/* tests/noise_filter_benchmark/v3.cu:32-90 (the K = 5 median the reference evaluated and left out of its
+ * server for speed): per channel the median of the 5x5 neighbourhood, zeros outside the image; not in-place. */
+int mi355_median5x5(mi355_core *core, const void *d_in, void *d_out);
+
 /* Batched form of the per-frame filters: nframes frames at d_in + t*stride_bytes (and d_in2 + t*stride_bytes
  * for the two-input filters) -> d_out + t*stride_bytes, one launch per kernel for the whole batch.
  * The *_BINARIZE ops compute one histogram and one two-max threshold per frame; the fused forms read
@@ -172,6 +176,7 @@ int mi355_conv3x3(mi355_core *core, const void *d_in, void *d_out);
 #define MI355_OP_HEAT_MAP 6                /* d_in = cur, d_in2 = prev: kernels.cu:243-270 */
 #define MI355_OP_RED_DENSE 7               /* d_in = cur, d_in2 = prev: test.cu:142-168 */
 #define MI355_OP_CONV3X3 8                 /* kernels.cu:97-136, not in place          */
+#define MI355_OP_MEDIAN5X5 9               /* noise_filter_benchmark/v3.cu:32-90, not in place */
 int mi355_filter_batch(mi355_core *core, int op, const void *d_in, const void *d_in2, void *d_out,
                        size_t stride_bytes, int nframes);
 

@@ -199,6 +199,45 @@ void ora_conv3x3(const uint8_t *in, uint8_t *out, int w, int h, const float *k) 
     }
 }
 
+/* tests/noise_filter_benchmark/v3.cu:32-47: the reference's swap sort, then the middle element. */
+static uint8_t ora_median_of(uint8_t *array, int n) {
+    int swapped = 1;
+    for (int a = 0; a < n && swapped; a++) {                     /* :34 */
+        swapped = 0;
+        for (int i = 0; i < n - 1; i++) {                        /* :36 */
+            if (array[i] > array[i + 1]) {                       /* :37 */
+                uint8_t tmp = array[i];
+                array[i] = array[i + 1];
+                array[i + 1] = tmp;
+                swapped = 1;
+            }
+        }
+    }
+    return array[n / 2];                                         /* :46 */
+}
+
+void ora_median5x5(const uint8_t *in, uint8_t *out, int w, int h) {
+    /* tests/noise_filter_benchmark/v3.cu:49-90 (K = 5): per channel, the median of the 5x5 neighbourhood
+     * with zeros outside the image (:61-69; the kernel leaves channel 2 of its halo unset, :68 writes
+     * channel 1 twice -- zero is what the code means and what is restated). */
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            for (int c = 0; c < 3; c++) {
+                uint8_t win[25];
+                int n = 0;
+                for (int i = 0; i < 5; i++) {                    /* :79 */
+                    for (int j = 0; j < 5; j++) {                /* :80 */
+                        int yy = y + i - 2, xx = x + j - 2;      /* :58-59, K/2 = 2 */
+                        win[n++] = (yy >= 0 && yy < h && xx >= 0 && xx < w)
+                                       ? in[((size_t)yy * w + xx) * 3 + c] : 0;
+                    }
+                }
+                out[((size_t)y * w + x) * 3 + c] = ora_median_of(win, 25);   /* :86-88 */
+            }
+        }
+    }
+}
+
 void ora_conv3x3_intacc(const int32_t *in, int32_t *out, int w, int h, const float *k) {
     /* tests/noise_filter_benchmark/cpu.cu:72-98 with K=3 */
     for (int i = 0; i < h; i++) {

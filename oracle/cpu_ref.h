@@ -62,6 +62,8 @@ void ora_gaussian_kernel(float *k, int K, float sigma);
 void ora_conv3x3(const uint8_t *in, uint8_t *out, int w, int h, const float *k);
 /* Secondary oracle, tests/noise_filter_benchmark/cpu.cu:72-98 (int accumulator that truncates
  * after every tap; int images). */
+/* tests/noise_filter_benchmark/v3.cu:32-90: 5x5 median per channel, zeros outside the image. */
+void ora_median5x5(const uint8_t *in, uint8_t *out, int w, int h);
 void ora_conv3x3_intacc(const int32_t *in, int32_t *out, int w, int h, const float *k);
 
 /* ---- a-7: heat map -----------------------------------------------------------------------

@@ -52,6 +52,8 @@ def lib():
     L.ora_gaussian_kernel.argtypes = [f32p, C.c_int, C.c_float]
     L.ora_conv3x3.restype = None
     L.ora_conv3x3.argtypes = [u8p, u8p, C.c_int, C.c_int, f32p]
+    L.ora_median5x5.restype = None
+    L.ora_median5x5.argtypes = [u8p, u8p, C.c_int, C.c_int]
     L.ora_conv3x3_intacc.restype = None
     L.ora_conv3x3_intacc.argtypes = [i32p, i32p, C.c_int, C.c_int, f32p]
     L.ora_heat_lut.restype = None
@@ -172,6 +174,13 @@ def conv3x3(img, w, h, k):
     img = _u8(img)
     out = np.empty_like(img)
     lib().ora_conv3x3(img, out, w, h, np.ascontiguousarray(k, dtype=np.float32))
+    return out
+
+
+def median5x5(img, w, h):
+    img = _u8(img)
+    out = np.empty_like(img)
+    lib().ora_median5x5(img, out, w, h)
     return out
 
 

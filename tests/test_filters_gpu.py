@@ -133,6 +133,30 @@ def test_conv3x3_column_strips(po, w, h):
             assert np.array_equal(d_o.cpu().numpy(), po.conv3x3(img, w, h, k))
 
 
+@pytest.mark.parametrize("w,h", [(64, 48), (1, 1), (2, 5), (5, 2), (65, 17), (131, 33), (640, 360)])
+def test_median5x5(po, w, h):
+    """tests/noise_filter_benchmark/v3.cu:32-90 restated (swap sort, middle element) against the selection
+    network of the kernel: random bytes, a constant frame (borders see the zero padding) and salt noise."""
+    rng = np.random.default_rng(5 * w + h)
+    n = 3 * w * h
+    salt = np.full(n, 90, np.uint8)
+    salt[rng.random(n) < 0.1] = 255
+    for img in (rng.integers(0, 256, n, dtype=np.uint8), np.full(n, 200, np.uint8), salt):
+        with CUDACore(w, h) as core:
+            d_o = dev_out(n)
+            core.median5x5(to_dev(img), d_o); core.synchronize()
+            assert np.array_equal(d_o.cpu().numpy(), po.median5x5(img, w, h))
+    with CUDACore(w, h, max_batch=3) as core:       # batched, with a frame stride larger than the frame
+        frames = rng.integers(0, 256, (3, n + 16), dtype=np.uint8)
+        d_in, d_out = to_dev(frames), torch.zeros((3, n + 16), dtype=torch.uint8, device=DEV)
+        core.filter_batch(lib.OP_MEDIAN5X5, d_in, d_out, 3, stride=n + 16)
+        core.synchronize()
+        got = d_out.cpu().numpy()
+        for t in range(3):
+            assert np.array_equal(got[t, :n], po.median5x5(frames[t, :n], w, h))
+            assert (got[t, n:] == 0).all()
+
+
 def test_conv_requires_kernel_and_out_of_place():
     with CUDACore(8, 8) as core:
         d = dev_out(192)

@@ -267,3 +267,24 @@ def test_wire_format_and_client_round_trip(po):
     assert np.array_equal(shown[-1], st)
     assert np.array_equal(counts, np.diff(o.astype(np.int64)))
     assert (np.abs(shown.astype(np.int16) - fr.astype(np.int16)) <= 20).all()
+
+
+def test_median5x5_restatement(po):
+    """tests/noise_filter_benchmark/v3.cu:32-90: against numpy's sort on a zero-padded copy, and two values a
+    reader can check by hand."""
+    rng = np.random.default_rng(2)
+    w, h = 11, 8
+    img = rng.integers(0, 256, 3 * w * h, dtype=np.uint8)
+    a = img.reshape(h, w, 3)
+    pad = np.zeros((h + 4, w + 4, 3), np.uint8)
+    pad[2:-2, 2:-2] = a
+    ref = np.empty_like(a)
+    for y in range(h):
+        for x in range(w):
+            for c in range(3):
+                ref[y, x, c] = np.sort(pad[y:y + 5, x:x + 5, c].reshape(-1))[12]
+    assert np.array_equal(po.median5x5(img, w, h).reshape(h, w, 3), ref)
+    const = po.median5x5(np.full(3 * 9 * 9, 77, np.uint8), 9, 9).reshape(9, 9, 3)
+    assert const[4, 4, 0] == 77          # interior: 25 equal values
+    assert const[0, 0, 0] == 0           # corner: 9 image values, 16 zeros -> the 13th smallest is a zero
+    assert const[0, 4, 1] == 77          # top edge: 15 image values, 10 zeros

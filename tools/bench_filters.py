@@ -41,6 +41,7 @@ def main():
         ("heat_map", lib.OP_HEAT_MAP, prev, 3 * N),
         ("red_dense", lib.OP_RED_DENSE, prev, 3 * N),
         ("conv3x3", lib.OP_CONV3X3, None, 2 * N),
+        ("median5x5", lib.OP_MEDIAN5X5, None, 2 * N),
     ]
     for name, op, second, alg in ops:
         for _ in range(3):
