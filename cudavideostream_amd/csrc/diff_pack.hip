@@ -424,11 +424,14 @@ __global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t
         carry += total;
     }
     // totals and the ticket are agent-scope atomics: the workgroups run on different XCDs, whose L2s are
-    // not coherent for plain accesses
+    // not coherent for plain accesses.  The total is ordered before the ticket by waiting for its store
+    // to complete, not by a release fence -- at agent scope a fence writes back the whole L2, which is full
+    // of k_diff_pack's fresh log lines (measured: 19 us per launch with the fence, see profiles/README.md).
     __shared__ uint32_t s_is_last;
     if (threadIdx.x == 0) {
         __hip_atomic_store(&totals[blockIdx.x], carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_is_last = mine == gridDim.x - 1;
     }
     __syncthreads();
