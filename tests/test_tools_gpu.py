@@ -56,3 +56,17 @@ def test_cpp_server_to_client_round_trip_over_the_c_abi(w, h, T, B):
     assert r["roundtrip"] == "ok" and r["max_abs_error"] <= 20
     assert r["wire_bytes"] == 4 * T + 5 * r["changed_bytes"]
     assert r["wire_bytes"] < r["raw_bytes"]
+
+
+CP = os.path.join(ROOT, "tools", "compat_pipe")
+
+
+@pytest.mark.skipif(not os.path.exists(CP), reason="tools/compat_pipe not built")
+@pytest.mark.parametrize("w,h,T", [(640, 360, 12), (97, 13, 7), (1920, 1080, 5)])
+def test_cpp_drop_in_class_pipelined_equals_blocking(w, h, T):
+    """tools/compat_pipe: diff::cuda::CUDACore (compat/) -- exec_submit/exec_wait with 3 frames in flight give
+    the same h_pos / h_xs / diff bytes per frame as the reference's blocking exec_core call."""
+    out = subprocess.run([CP, str(w), str(h), str(T)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["compat_pipe"] == "ok" and r["changed_bytes"] > 0
