@@ -58,6 +58,38 @@ def main():
         print(json.dumps({"filter": name, "us_per_frame": round(us, 3), "frames_per_s": round(1e6 / us, 1),
                           "algorithmic_bytes_per_frame": int(alg), "achieved_gbps": round(gbps, 1),
                           "frac_of_8TBps": round(gbps / 8000.0, 4), "batch": B}), flush=True)
+    # BASELINE configs 3 and 4 end to end (what the server does with a frame when the filter is enabled,
+    # kernels.cu:457-520), on the same resident batch: the visualiser's frame AND the packed diff stream
+    cap = B * n // 4
+    d_off = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    d_xs = torch.empty(cap, dtype=torch.int32, device=dev)
+    d_df = torch.empty(cap, dtype=torch.uint8, device=dev)
+    filt = torch.empty((B, n), dtype=torch.uint8, device=dev)
+
+    def config3():   # weighted gray + histogram + two-max + binarize (visualiser 5), then diff+threshold+pack
+        core.filter_batch(lib.OP_GRAY_WEIGHTED_BINARIZE, cur, out, B)
+        core.diff_stream_batch(cur, B, d_off, d_xs, d_df, cap)
+
+    def config4():   # 3x3 noise filter, diff+threshold+pack of the filtered frames, red motion map
+        core.filter_batch(lib.OP_CONV3X3, cur, filt, B)
+        core.diff_stream_batch(filt, B, d_off, d_xs, d_df, cap)
+        core.filter_batch(lib.OP_RED_DENSE, filt[1:], out, B - 1, d_in2=filt[:-1])
+
+    for name, fn in (("config 3: gray-weighted + binarize + diff/threshold/pack", config3),
+                     ("config 4: noise filter + diff/threshold/pack + red motion map", config4)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(a.reps):
+            fn()
+        ev1.record()
+        torch.cuda.synchronize()
+        us = ev0.elapsed_time(ev1) * 1e3 / (a.reps * B)
+        print(json.dumps({"chain": name, "us_per_frame": round(us, 3), "frames_per_s": round(1e6 / us, 1),
+                          "batch": B, "changed_bytes_per_frame": round((int(d_off[B].item()) & 0xFFFFFFFF) / B, 1)}),
+              flush=True)
     core.close()
     cpu_reference_line(W, H)
 
