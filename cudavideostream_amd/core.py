@@ -242,6 +242,12 @@ class CUDACore:
     def red_overlap(self, d_img, d_xs, d_count=None, count=0):
         _l.check(self._lib.mi355_red_overlap(self._h, _ptr(d_img), _ptr(d_xs), _ptr(d_count), count))
 
+    def red_stream_batch(self, d_offsets, d_xs, nframes, d_frames, clear=True, stride=None):
+        """Red motion maps of a batch from its packed stream (kernels.cu:513-518 per frame)."""
+        stride = self.total if stride is None else stride
+        _l.check(self._lib.mi355_red_stream_batch(self._h, _ptr(d_offsets), _ptr(d_xs), nframes, _ptr(d_frames),
+                                                  stride, int(bool(clear))))
+
     def conv3x3(self, d_in, d_out):
         _l.check(self._lib.mi355_conv3x3(self._h, _ptr(d_in), _ptr(d_out)))
 

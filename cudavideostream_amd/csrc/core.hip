@@ -500,6 +500,19 @@ int mi355_red_overlap(mi355_core *c, void *d_img, const void *d_xs, const void *
     return MI355_OK;
 }
 
+int mi355_red_stream_batch(mi355_core *c, const void *d_offsets, const void *d_xs, int nframes, void *d_frames,
+                           size_t stride_bytes, int clear) {
+    if (!c) return fail(MI355_ERR_INVALID, "null core");
+    if (nframes < 0) return fail(MI355_ERR_INVALID, "nframes < 0");
+    if (nframes == 0 || c->n == 0) return MI355_OK;
+    if (!d_offsets || !d_xs || !d_frames) return fail(MI355_ERR_INVALID, "null argument");
+    if (stride_bytes < c->n) return fail(MI355_ERR_INVALID, "stride_bytes < frame bytes");
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(launch_red_stream((uint8_t *)d_frames, (const uint32_t *)d_offsets, (const int32_t *)d_xs, c->n, clear != 0,
+                              FrameBatch{stride_bytes, nframes}, c->stream));
+    return MI355_OK;
+}
+
 int mi355_conv3x3(mi355_core *c, const void *d_in, void *d_out) {
     if (!c || (c->n && (!d_in || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
     if (d_in == d_out && c->n) return fail(MI355_ERR_INVALID, "conv3x3 cannot run in place");

@@ -454,6 +454,33 @@ hipError_t launch_red_overlap(uint8_t *img, const int32_t *xs, const uint32_t *d
     return hipGetLastError();
 }
 
+// Batched form over a packed stream: frame t's red map from its own entries xs[offsets[t] .. offsets[t+1])
+// (grid.y = frame).  The frames are zeroed (kernels.cu:513) or left as they are (overlap form, :517) by the
+// caller.
+__global__ __launch_bounds__(256) void k_red_stream(uint8_t *out, size_t stride, const uint32_t *offsets,
+                                                    const int32_t *xs, uint32_t nbytes) {
+    const uint32_t first = offsets[blockIdx.y], n = offsets[blockIdx.y + 1] - first;
+    uint8_t *img = out + (size_t)blockIdx.y * stride;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t x = (uint32_t)xs[first + i];
+        const uint32_t at = x + (2u - x % 3u);                     // kernels.cu:273-281
+        if (at < nbytes) img[at] = 255;
+    }
+}
+
+hipError_t launch_red_stream(uint8_t *out, const uint32_t *offsets, const int32_t *xs, uint32_t nbytes, bool clear,
+                             FrameBatch fb, hipStream_t s) {
+    if (fb.nframes <= 0 || nbytes == 0) return hipSuccess;
+    if (clear) {
+        hipError_t e = fb.stride == nbytes
+                           ? hipMemsetAsync(out, 0, (size_t)fb.nframes * nbytes, s)
+                           : hipMemset2DAsync(out, fb.stride, 0, nbytes, (size_t)fb.nframes, s);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_red_stream, dim3(64, (unsigned)fb.nframes), dim3(256), 0, s, out, fb.stride, offsets, xs, nbytes);
+    return hipGetLastError();
+}
+
 // ---- 3x3 noise filter: kernels.cu:97-136 --------------------------------------------------------------
 // out[y][x][c] = (uint8) sum_{i,j} k[3i+j] * in[y+i-1][x+j-1][c], zero outside the image, float
 // accumulator, taps in i-major / j-minor order, one multiply then one add per tap.

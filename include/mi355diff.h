@@ -157,6 +157,11 @@ int mi355_red_dense(mi355_core *core, const void *d_cur, const void *d_prev, voi
  * (uint32 on the device) when d_count != NULL, else `count` is used. */
 int mi355_red_overlap(mi355_core *core, void *d_img, const void *d_xs, const void *d_count,
                       uint32_t count);
+/* The same from a packed stream, for a batch: frame t (at d_frames + t*stride_bytes) gets R = 255 for every
+ * pixel owning one of its entries xs[offsets[t] .. offsets[t+1]).  clear != 0 zeroes the frames first
+ * (NOISE_VISUALIZER 2, kernels.cu:513); clear == 0 paints onto what they hold (NOISE_VISUALIZER 3, :517). */
+int mi355_red_stream_batch(mi355_core *core, const void *d_offsets, const void *d_xs, int nframes,
+                           void *d_frames, size_t stride_bytes, int clear);
 /* kernels.cu:97-136: 3x3 convolution with the kernel of mi355_set_conv_kernel; not in-place. */
 int mi355_conv3x3(mi355_core *core, const void *d_in, void *d_out);
 

@@ -8,7 +8,7 @@ DEV = "cuda:0"
 
 _DEVICE_CALLS = {"diff_stream_batch", "diff_pairs_batch", "diff_stream_wire_batch", "apply_batch",
                  "apply_wire_batch", "merge_parts", "int_diff", "gray_avg", "gray_weighted", "binarize_chain",
-                 "heat_map", "red_dense", "red_overlap", "conv3x3", "median5x5", "filter_batch"}
+                 "heat_map", "red_dense", "red_overlap", "red_stream_batch", "conv3x3", "median5x5", "filter_batch"}
 
 
 class CUDACore(_CUDACore):

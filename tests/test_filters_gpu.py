@@ -182,6 +182,28 @@ def test_red_overlap(po):
         assert np.array_equal(d_img.cpu().numpy(), po.red_overlap(base, xs))
 
 
+@pytest.mark.parametrize("clear", [True, False])
+def test_red_stream_batch(po, clear):
+    """The red motion maps of a whole batch from its packed stream = red_black_map_overlap per frame
+    (kernels.cu:273-281,513-518), on zeroed frames or on top of given ones, with a padded frame stride."""
+    w, h, T = 96, 40, 5
+    n = 3 * w * h
+    base, frames = synth.webcam_stream(T, w, h, seed=90)
+    off, xs, df, _ = po.diff_stream(frames, base)
+    rng = np.random.default_rng(0)
+    canvas = rng.integers(0, 200, (T, n + 32), dtype=np.uint8)
+    with CUDACore(w, h, max_batch=T) as core:
+        d_canvas = to_dev(canvas)
+        core.red_stream_batch(to_dev(off.view(np.int32)), to_dev(np.append(xs, np.int32(0))), T, d_canvas,
+                              clear=clear, stride=n + 32)
+        core.synchronize()
+        got = d_canvas.cpu().numpy()
+        for t in range(T):
+            start = np.zeros(n, np.uint8) if clear else canvas[t, :n]
+            assert np.array_equal(got[t, :n], po.red_overlap(start, xs[off[t]:off[t + 1]]))
+            assert np.array_equal(got[t, n:], canvas[t, n:])      # the padding between frames is untouched
+
+
 # ---- exec_core: the per-frame host path (kernels.cu:430-525) ---------------------------------------
 
 def oracle_exec(po, frame, state, vis, k, noise_filter, w, h):

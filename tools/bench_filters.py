@@ -73,7 +73,7 @@ def main():
     def config4():   # 3x3 noise filter, diff+threshold+pack of the filtered frames, red motion map
         core.filter_batch(lib.OP_CONV3X3, cur, filt, B)
         core.diff_stream_batch(filt, B, d_off, d_xs, d_df, cap)
-        core.filter_batch(lib.OP_RED_DENSE, filt[1:], out, B - 1, d_in2=filt[:-1])
+        core.red_stream_batch(d_off, d_xs, B, out)   # from the packed indices, as kernels.cu:513 does
 
     for name, fn in (("config 3: gray-weighted + binarize + diff/threshold/pack", config3),
                      ("config 4: noise filter + diff/threshold/pack + red motion map", config4)):
