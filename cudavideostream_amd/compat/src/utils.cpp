@@ -1,4 +1,15 @@
-// compat/src/utils.cpp -- diff::utils::matsz::area (reference server/src/utils.cpp:5-7).
+// compat/src/utils.cpp -- the one out-of-line member of diff::utils::matsz the reference's server.cpp
+// leaves undefined when kernels.cu and its utils.o are replaced by this drop-in (SURVEY.md section 8b lists the
+// mangled name): the number of pixels of a height x width size (reference server/src/utils.cpp:5-7).
 #include "../include/utils.hpp"
 
-int diff::utils::matsz::area() { return width * height; }
+namespace diff {
+namespace utils {
+
+int matsz::area() {
+    const int pixels = height * width;
+    return pixels;
+}
+
+}  // namespace utils
+}  // namespace diff
