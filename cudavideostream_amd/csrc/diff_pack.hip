@@ -26,8 +26,9 @@
 //                 one 16-byte meta word keeps {candidate ballot, flagged-byte count, log position}.
 //   k_scan_groups: per frame, flagged bytes before every group of 64 tiles; its last workgroup scans the
 //               frame totals into offsets[0..T].
-//   k_expand    : one workgroup per (frame, 64 tiles): turns records into the caller's packed,
-//                 frame-major, ascending (xs, diff) arrays through an LDS stage and coalesced stores.
+//   k_expand    : one wave per (frame, 16 tiles): turns records into the caller's packed, frame-major,
+//                 ascending (xs, diff) arrays -- or the socket's byte stream -- through an LDS stage
+//                 and coalesced stores.
 // No spin waits; the only inter-workgroup communication is the completion ticket of k_scan_groups;
 // results are independent of dispatch order.
 #include "internal.h"
@@ -370,7 +371,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *l
     return r;
 }
 
-// A *group* is the kXTiles consecutive tiles one k_expand workgroup owns; the expander needs, per frame,
+// A *group* is kXTiles consecutive tiles (four k_expand waves); the expander needs, per frame,
 // the bytes in the groups before its own and rebuilds everything finer from the meta words.
 constexpr uint32_t kXTiles = 64;          // = one wave of k_scan_groups per group
 constexpr uint32_t kScanChunk = 1024;     // groups scanned per pass of k_scan_groups
@@ -463,38 +464,37 @@ hipError_t launch_scan(const uint4 *meta, uint32_t *groff, uint32_t *totals, uin
 }
 
 // ---- expand: records -> packed frame-major (xs, diff) -------------------------------------------------
-// grid = (ceil(W/64), T), block = 256.  A workgroup owns 64 consecutive tiles of ONE frame: its output
-// is one contiguous range of the frame's segment, so the entries are staged in LDS in output order
-// and leave with fully coalesced stores (a dozen store instructions per workgroup instead of two
-// scattered ones per flagged byte).  A record is found from its index in the workgroup: tile by a
-// 6-step search of the record prefix, source lane as the k-th set bit of the tile's candidate ballot.
-// A pass covers up to 8 x 256 records; all record loads of a pass are issued before any is used and
-// the byte counts of two rounds share a register, so a pass costs 4 DPP scans and two barriers.
-// 1080p webcam-like input: ~1200 records and ~1500 entries per workgroup, one pass.
+// grid = (ceil(W/16) rounded up to a multiple of 8, T), block = 64: one wave owns 16 consecutive tiles of
+// ONE frame, i.e. one contiguous range of that frame's output.  The wave loads the meta words of its whole
+// 64-tile group (the scan kernel gives the bytes in front of the group, the wave adds those in front of
+// its own 16 tiles) and keeps the per-tile facts in registers (readlane / ds_bpermute).  For every
+// candidate lane of its tiles it writes (tile, lane) at the record's rank into a small LDS table (ballot +
+// mbcnt), so that "record r of the wave" is found with one LDS read; 64 records are loaded per round,
+// their 16-bit maps of nonzero (= flagged) bytes come from v_dot4_u32_u8, the entry offsets from one DPP
+// scan; entries are staged in LDS in output order and leave with coalesced stores.  No barriers.
+// Measured (profiles/README.md): the kernel is bound by the log's round trip through the memory system
+// (without its record reads it takes 0.13 ms instead of 0.23 ms per 256-frame batch -- and the NEXT
+// k_diff_pack then takes 0.09 ms longer, because its record stores no longer find their lines cached);
+// instruction count, occupancy, barriers and XCD placement were each varied without effect.
 __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t v) {   // 0x80 per nonzero byte
     return (((v & kL) + kL) | v) & kH;
 }
 
-#ifndef MI355_XROUNDS
-#define MI355_XROUNDS 3
-#endif
-constexpr int kXRounds = MI355_XROUNDS;   // rounds of 256 records per pass (even)
 #ifndef MI355_XLIGHT
 #define MI355_XLIGHT 4
 #endif
 constexpr uint32_t kXLight = MI355_XLIGHT;   // records with more flagged bytes than this are "heavy"
 constexpr int kXHeavyMax = 12;               // more heavy records than this in a wave: everybody walks
-constexpr uint32_t kXEntries = 4096;   // LDS staging: a sparse workgroup's whole output, or one round (256 records) of a dense one
 
 // WIRE: the entries leave in the sender's byte stream instead (server/src/threads.cpp:227-229): frame t
 // is {u32 n, i32 xs[n], u8 diff[n]} at byte 4t + 5*offsets[t] of a.wire, so index and payload sections
 // start at arbitrary byte addresses (gfx950 global stores need no alignment).
 __device__ __forceinline__ void store_u32_unaligned(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 
-// Entries [first, first + count) of a workgroup, staged in LDS at s_xs/s_df[0..count), leave with coalesced
+// Entries [first, first + count) of a workgroup of NT threads, staged in LDS at s_xs/s_df[0..count), leave with coalesced
 // stores: one dword per index, and the differences as whole dwords too (byte stores only for the up to
 // three bytes before and after the dword-aligned body of the destination).
-template <bool WIRE>
+template <bool WIRE, uint32_t NT>
 __device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint16_t *s_xs, const uint8_t *s_df,
                                               uint32_t first, uint32_t count, uint32_t xs0, uint32_t dst0,
                                               uint8_t *w_xs, uint8_t *w_df, size_t w_room) {
@@ -510,12 +510,12 @@ __device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint16_
         xsp = (uint8_t *)(a.out_xs + d);
         dfp = a.out_diff + d;
     }
-    for (uint32_t i = threadIdx.x; i < n; i += 256) store_u32_unaligned(xsp + 4 * (size_t)i, xs0 + s_xs[i]);
+    for (uint32_t i = threadIdx.x; i < n; i += NT) store_u32_unaligned(xsp + 4 * (size_t)i, xs0 + s_xs[i]);
     const uint32_t lead = (4u - (uint32_t)((uintptr_t)dfp & 3u)) & 3u;
     const uint32_t head = lead < n ? lead : n;
     const uint32_t body = (n - head) >> 2;
     if (threadIdx.x < head) dfp[threadIdx.x] = s_df[threadIdx.x];
-    for (uint32_t k = threadIdx.x; k < body; k += 256) {
+    for (uint32_t k = threadIdx.x; k < body; k += NT) {
         const uint8_t *q = s_df + head + 4 * k;
         const uint32_t v = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
         *reinterpret_cast<uint32_t *>(dfp + head + 4 * (size_t)k) = v;
@@ -524,186 +524,134 @@ __device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint16_
     if (tail < n) dfp[tail] = s_df[tail];
 }
 
-// The records of a workgroup, ROUNDS x 256 per pass: all record loads of a pass are issued before any is
-// used.  Sparse workgroups (DENSE = false) stage their whole output in LDS and flush it at the end;
-// dense ones stage and flush one round at a time.
-template <bool WIRE, int ROUNDS, bool DENSE>
-__device__ __forceinline__ void expand_records(const ExpandArgs &a, uint32_t nrec, uint32_t tile0, uint32_t dst0,
-                                               const uint16_t *s_src, const uint32_t *s_rbase, uint32_t *s_wave,
-                                               uint16_t *s_xs, uint8_t *s_df, uint8_t *w_xs, uint8_t *w_df,
-                                               size_t w_room) {
-    static_assert(ROUNDS <= 4, "s_wave holds two packed words per wave");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t carry = 0;   // entries of earlier passes
-    for (uint32_t base = 0; base < nrec; base += 256 * ROUNDS) {
-        uint4 rec[ROUNDS];
-        uint32_t src16[ROUNDS];   // ((tile - tile0) << 6 | lane) * 16 = first byte of the record's lane, relative
-#pragma unroll
-        for (int j = 0; j < ROUNDS; j++) {
-            rec[j] = make_uint4(0, 0, 0, 0);
-            src16[j] = 0;
-            const uint32_t r = base + (uint32_t)j * 256u + threadIdx.x;   // round j: contiguous records
-            if (r < nrec) {
-                const uint32_t src = s_src[r];
-                const uint32_t sgm = src >> 6;
-                src16[j] = src * 16u;
-                rec[j] = a.rec[rec_index(r + s_rbase[sgm], tile0 + sgm, a.ntiles)];
-            }
-        }
-        // 16-bit maps of the nonzero (= flagged) bytes: v_dot4 gathers the four 0x80 marks of a dword
-        // into 4 adjacent bits
-        uint32_t m16[ROUNDS], cnt[ROUNDS], incl[(ROUNDS + 1) / 2];
-#pragma unroll
-        for (int j = 0; j < ROUNDS; j++) {
-            const uint32_t g0 = __builtin_amdgcn_udot4(nonzero_bytes(rec[j].x), 0x08040201u, 0u, false);
-            const uint32_t g1 = __builtin_amdgcn_udot4(nonzero_bytes(rec[j].y), 0x08040201u, 0u, false);
-            const uint32_t g2 = __builtin_amdgcn_udot4(nonzero_bytes(rec[j].z), 0x08040201u, 0u, false);
-            const uint32_t g3 = __builtin_amdgcn_udot4(nonzero_bytes(rec[j].w), 0x08040201u, 0u, false);
-            m16[j] = (g0 + (g1 << 4) + (g2 << 8) + (g3 << 12)) >> 7;
-            cnt[j] = (uint32_t)__builtin_popcount(m16[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < (ROUNDS + 1) / 2; j++) {      // a round total is at most 256*16 = 4096
-            const uint32_t hi = 2 * j + 1 < ROUNDS ? cnt[(2 * j + 1) % ROUNDS] : 0u;
-            incl[j] = (uint32_t)wave_inclusive_scan((int)(cnt[2 * j] | (hi << 16)));
-            if (lane == 63) s_wave[wave * 2 + j] = incl[j];
-        }
-        __syncthreads();
-        uint32_t run = carry;   // entries before round j (all waves), then before this wave in round j
-#pragma unroll
-        for (int j = 0; j < ROUNDS; j++) {
-            const int sh = (j & 1) * 16;
-            uint32_t before = 0, round_total = 0;
-#pragma unroll
-            for (int w = 0; w < 4; w++) {
-                const uint32_t v = (s_wave[w * 2 + j / 2] >> sh) & 0xffffu;
-                if (w < wave) before += v;
-                round_total += v;
-            }
-            const uint32_t round_first = run;   // entries of the workgroup before this round
-            // index in the LDS stage: within the workgroup (sparse) or within the round (dense)
-            uint32_t e = (DENSE ? 0u : run) + before + ((incl[j / 2] >> sh) & 0xffffu) - cnt[j];
-            run += round_total;
-            uint32_t m = m16[j];
-            // A lane walks the set bits of its record, so a wave pays for its densest record: a few
-            // records with many flagged bytes (the edges of a moving object among isolated bytes) are
-            // taken out of the walk and emitted one at a time by 16 lanes, one byte each.
-            const uint64_t heavy = __ballot(cnt[j] > kXLight);
-            const bool coop = __builtin_popcountll(heavy) <= kXHeavyMax;
-            const uint32_t e0 = e;
-            if (coop && cnt[j] > kXLight) m = 0;
-            while (m) {
-                const int b = __builtin_ctz(m);
-                m &= m - 1;
-                const uint32_t dw = b < 8 ? (b < 4 ? rec[j].x : rec[j].y) : (b < 12 ? rec[j].z : rec[j].w);
-                s_xs[e] = (uint16_t)(src16[j] + (uint32_t)b);                    // kernels.cu:315
-                s_df[e] = (uint8_t)(dw >> (8 * (b & 3)));                        // kernels.cu:314
-                ++e;
-            }
-            if (coop) {
-                const uint32_t b = (uint32_t)lane & 15u;
-                for (uint64_t h = heavy; h; h &= h - 1) {
-                    const int hl = __builtin_ctzll(h);
-                    const uint32_t r0 = __builtin_amdgcn_readlane(rec[j].x, hl);
-                    const uint32_t r1 = __builtin_amdgcn_readlane(rec[j].y, hl);
-                    const uint32_t r2 = __builtin_amdgcn_readlane(rec[j].z, hl);
-                    const uint32_t r3 = __builtin_amdgcn_readlane(rec[j].w, hl);
-                    const uint32_t mm = __builtin_amdgcn_readlane(m16[j], hl);
-                    const uint32_t ee = __builtin_amdgcn_readlane(e0, hl);
-                    const uint32_t sb = __builtin_amdgcn_readlane(src16[j], hl);
-                    if (lane < 16 && ((mm >> b) & 1u)) {
-                        const uint32_t pos = ee + (uint32_t)__builtin_popcount(mm & ((1u << b) - 1u));
-                        const uint32_t dw = b < 8 ? (b < 4 ? r0 : r1) : (b < 12 ? r2 : r3);
-                        s_xs[pos] = (uint16_t)(sb + b);
-                        s_df[pos] = (uint8_t)(dw >> (8 * (b & 3)));
-                    }
-                }
-            }
-            if (DENSE) {   // the round leaves now
-                __syncthreads();
-                flush_entries<WIRE>(a, s_xs, s_df, round_first, round_total, tile0 * kTileBytes, dst0, w_xs, w_df, w_room);
-            }
-        }
-        carry = run;
-        __syncthreads();   // s_wave is reused by the next pass; staged entries are complete after the last
-    }
-}
+constexpr uint32_t kWTiles = 16;       // tiles per single-wave workgroup
+constexpr uint32_t kWStage = 1024;     // entries staged per wave = the most a round of 64 records can hold (5 KB of LDS per wave in all)
 
 template <bool WIRE>
-__global__ __launch_bounds__(256) void k_expand(const ExpandArgs a) {
-    __shared__ uint64_t s_mask[kXTiles];
-    __shared__ uint32_t s_rexcl[kXTiles];                 // records of the workgroup before this tile
-    __shared__ uint32_t s_rbase[kXTiles];                 // log position of the tile's first record - s_rexcl
-    __shared__ uint16_t s_src[kXTiles * 64];              // record r of the workgroup -> (tile << 6) | source lane
-    __shared__ uint32_t s_wave[4 * 2];                    // per wave: packed byte totals per round pair
-    __shared__ uint32_t s_total, s_nrec;                  // entries / records of this workgroup
-    __shared__ uint16_t s_xs[kXEntries];                  // byte index relative to the workgroup's first tile
-    __shared__ uint8_t s_df[kXEntries];
+__global__ __launch_bounds__(64) void k_expand(const ExpandArgs a) {
+    __shared__ uint16_t s_src[kWTiles * 64];
+    __shared__ uint16_t s_xs[kWStage];
+    __shared__ uint8_t s_df[kWStage];
+    const int lane = threadIdx.x;
     const int t = blockIdx.y;
-    const uint32_t tile0 = blockIdx.x * kXTiles;
+    const uint32_t sub = blockIdx.x, group = sub >> 2, q = sub & 3u;
+    const uint32_t tile0 = sub * kWTiles, gtile0 = group * kXTiles;
+    const uint32_t ngroups = (a.ntiles + kXTiles - 1) / kXTiles;
+    if (tile0 >= a.ntiles) return;   // grid.x is padded to a multiple of 8 (see launch_expand)
     const size_t row = (size_t)t * a.ntiles;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // issued first: needed only when the entries leave, so their latency hides behind everything else
     const uint32_t off_t = a.offsets[t];
-    const uint32_t dst0 = off_t + a.groff[(size_t)t * gridDim.x + blockIdx.x];   // < 2^32: the batch total is below 2^32
-    uint8_t *w_xs = nullptr, *w_df = nullptr;   // WIRE: this workgroup's first index / payload byte
-    size_t w_room = 0;                          // WIRE: entries of this workgroup that fit in a.capacity bytes
+    const uint32_t goff = a.groff[(size_t)t * ngroups + group];
+    uint32_t n_t = 0;
+    size_t head = 0;
     if (WIRE) {
-        const uint32_t n_t = a.offsets[t + 1] - off_t;
-        const size_t head = 4 * (size_t)t + 5 * (size_t)off_t;
-        const size_t end = head + 4 + 5 * (size_t)n_t;   // a frame is written whole or (payload) not at all
-        if (blockIdx.x == 0 && threadIdx.x == 0 && head + 4 <= a.capacity) store_u32_unaligned(a.wire + head, n_t);
+        n_t = a.offsets[t + 1] - off_t;
+        head = 4 * (size_t)t + 5 * (size_t)off_t;
+        if (sub == 0 && lane == 0 && head + 4 <= a.capacity) store_u32_unaligned(a.wire + head, n_t);
+    }
+    // lane L <-> tile gtile0 + L of the group; lanes 16q .. 16q+15 are this wave's tiles
+    uint4 m = make_uint4(0, 0, 0, 0);
+    if (gtile0 + (uint32_t)lane < a.ntiles) m = a.meta[row + gtile0 + (uint32_t)lane];
+    const uint64_t mask = (uint64_t)m.x | ((uint64_t)m.y << 32);
+    const bool mine = ((uint32_t)lane >> 4) == q;
+    const uint32_t nr = mine ? (uint32_t)__builtin_popcountll(mask) : 0u;
+    const uint32_t rincl = (uint32_t)wave_inclusive_scan((int)nr);
+    const uint32_t bincl = (uint32_t)wave_inclusive_scan((int)m.z);
+    const uint32_t nrec = (uint32_t)__builtin_amdgcn_readlane((int)rincl, 63);
+    if (nrec == 0) return;
+    const uint32_t before = q ? (uint32_t)__builtin_amdgcn_readlane((int)bincl, (int)(16u * q - 1u)) : 0u;
+    const uint32_t dst0 = off_t + goff + before;   // < 2^32: the batch total is below 2^32
+    const uint32_t rexcl = rincl - nr;             // records of this wave before the lane's tile
+    const uint32_t rbase = m.w - rexcl;            // + record index in the wave = log position of the record
+    uint8_t *w_xs = nullptr, *w_df = nullptr;
+    size_t w_room = 0;
+    if (WIRE) {
+        const size_t end = head + 4 + 5 * (size_t)n_t;
         const uint32_t seg = dst0 - off_t;
         w_xs = a.wire + head + 4 + 4 * (size_t)seg;
         w_df = a.wire + head + 4 + 4 * (size_t)n_t + seg;
         w_room = end <= a.capacity ? (size_t)n_t : 0;
     }
-
-    if (wave == 0) {   // all 64 lanes take part in the DPP scans; lanes >= kXTiles carry zeros
-        const uint32_t tile = tile0 + (uint32_t)lane;
-        uint4 m = make_uint4(0, 0, 0, 0);
-        if ((uint32_t)lane < kXTiles && tile < a.ntiles) m = a.meta[row + tile];
-        const uint64_t mask = (uint64_t)m.x | ((uint64_t)m.y << 32);
-        const uint32_t nr = (uint32_t)__builtin_popcountll(mask);
-        const uint32_t rincl = (uint32_t)wave_inclusive_scan((int)nr);
-        const uint32_t bytes = (uint32_t)wave_inclusive_scan((int)m.z);
-        if ((uint32_t)lane < kXTiles) {
-            s_mask[lane] = mask;
-            s_rexcl[lane] = rincl - nr;
-            s_rbase[lane] = m.w - (rincl - nr);
-        }
-        if (lane == 63) { s_total = bytes; s_nrec = rincl; }
-    }
-    __syncthreads();
-    const uint32_t nrec = s_nrec;
-    if (nrec == 0) return;
-    const uint32_t total = s_total;
-    const bool staged = total <= kXEntries;
-    // where each record of the workgroup comes from: a wave walks its 16 tiles, candidate lanes write their
-    // (tile, lane) at the record's rank -- replaces a search per record
+    // where each record of the wave comes from: candidate lanes write (tile, lane) at the record's rank
 #pragma unroll 4
-    for (uint32_t i = 0; i < kXTiles / 4; i++) {
-        const uint32_t sgm = (uint32_t)wave * (kXTiles / 4) + i;
-        const uint64_t mask = s_mask[sgm];
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        if ((mask >> lane) & 1) s_src[s_rexcl[sgm] + rank] = (uint16_t)((sgm << 6) | (uint32_t)lane);
+    for (uint32_t i = 0; i < kWTiles; i++) {
+        const int L = (int)(16u * q + i);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mask, L);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mask >> 32), L);
+        const uint32_t rx = (uint32_t)__builtin_amdgcn_readlane((int)rexcl, L);
+        const uint64_t mk = (uint64_t)lo | ((uint64_t)hi << 32);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+        if ((mk >> lane) & 1) s_src[rx + rank] = (uint16_t)((i << 6) | (uint32_t)lane);
     }
-    __syncthreads();
-
-    if (staged) {
-        expand_records<WIRE, kXRounds, false>(a, nrec, tile0, dst0, s_src, s_rbase, s_wave, s_xs, s_df, w_xs, w_df, w_room);
-        flush_entries<WIRE>(a, s_xs, s_df, 0u, total, tile0 * kTileBytes, dst0, w_xs, w_df, w_room);
-    } else {
-        expand_records<WIRE, 1, true>(a, nrec, tile0, dst0, s_src, s_rbase, s_wave, s_xs, s_df, w_xs, w_df, w_room);
+    const uint32_t xs_base = tile0 * kTileBytes;
+    uint32_t carry = 0, flushed = 0;   // entries emitted / already stored
+    for (uint32_t base = 0; base < nrec; base += 64) {
+        const uint32_t r = base + (uint32_t)lane;
+        const uint32_t src = r < nrec ? s_src[r] : 0u;
+        const uint32_t sgm = src >> 6;
+        // every lane takes part in the permute; the value comes from the lane that holds tile sgm of this wave
+        const uint32_t rb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u * q + sgm) * 4u), (int)rbase);
+        const uint32_t src16 = src * 16u;
+        uint4 rec = make_uint4(0, 0, 0, 0);
+        if (r < nrec) rec = a.rec[rec_index(r + rb, tile0 + sgm, a.ntiles)];
+        const uint32_t g0 = __builtin_amdgcn_udot4(nonzero_bytes(rec.x), 0x08040201u, 0u, false);
+        const uint32_t g1 = __builtin_amdgcn_udot4(nonzero_bytes(rec.y), 0x08040201u, 0u, false);
+        const uint32_t g2 = __builtin_amdgcn_udot4(nonzero_bytes(rec.z), 0x08040201u, 0u, false);
+        const uint32_t g3 = __builtin_amdgcn_udot4(nonzero_bytes(rec.w), 0x08040201u, 0u, false);
+        const uint32_t m16 = (g0 + (g1 << 4) + (g2 << 8) + (g3 << 12)) >> 7;
+        const uint32_t cnt = (uint32_t)__builtin_popcount(m16);
+        const uint32_t incl = (uint32_t)wave_inclusive_scan((int)cnt);
+        const uint32_t round_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (carry - flushed + round_total > kWStage) {   // wave-uniform: make room
+            flush_entries<WIRE, 64>(a, s_xs, s_df, flushed, carry - flushed, xs_base, dst0, w_xs, w_df, w_room);
+            flushed = carry;
+        }
+        uint32_t e = carry - flushed + incl - cnt;        // index in the LDS stage
+        carry += round_total;
+        uint32_t mm = m16;
+        const uint64_t heavy = __ballot(cnt > kXLight);
+        const bool coop = __builtin_popcountll(heavy) <= kXHeavyMax;
+        const uint32_t e0 = e;
+        if (coop && cnt > kXLight) mm = 0;
+        while (mm) {
+            const int b = __builtin_ctz(mm);
+            mm &= mm - 1;
+            const uint32_t dw = b < 8 ? (b < 4 ? rec.x : rec.y) : (b < 12 ? rec.z : rec.w);
+            s_xs[e] = (uint16_t)(src16 + (uint32_t)b);                       // kernels.cu:315
+            s_df[e] = (uint8_t)(dw >> (8 * (b & 3)));                        // kernels.cu:314
+            ++e;
+        }
+        if (coop) {
+            const uint32_t b = (uint32_t)lane & 15u;
+            for (uint64_t h = heavy; h; h &= h - 1) {
+                const int hl = __builtin_ctzll(h);
+                const uint32_t r0 = __builtin_amdgcn_readlane(rec.x, hl);
+                const uint32_t r1 = __builtin_amdgcn_readlane(rec.y, hl);
+                const uint32_t r2 = __builtin_amdgcn_readlane(rec.z, hl);
+                const uint32_t r3 = __builtin_amdgcn_readlane(rec.w, hl);
+                const uint32_t hm = __builtin_amdgcn_readlane(m16, hl);
+                const uint32_t ee = __builtin_amdgcn_readlane(e0, hl);
+                const uint32_t sb = __builtin_amdgcn_readlane(src16, hl);
+                if (lane < 16 && ((hm >> b) & 1u)) {
+                    const uint32_t pos = ee + (uint32_t)__builtin_popcount(hm & ((1u << b) - 1u));
+                    const uint32_t dw = b < 8 ? (b < 4 ? r0 : r1) : (b < 12 ? r2 : r3);
+                    s_xs[pos] = (uint16_t)(sb + b);
+                    s_df[pos] = (uint8_t)(dw >> (8 * (b & 3)));
+                }
+            }
+        }
     }
+    flush_entries<WIRE, 64>(a, s_xs, s_df, flushed, carry - flushed, xs_base, dst0, w_xs, w_df, w_room);
 }
 
 hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s) {
-    const dim3 grid((a.ntiles + kXTiles - 1) / kXTiles, nframes);
+    // Workgroups go to the 8 XCDs round-robin by linear id: with grid.x a multiple of 8 the workgroups of one
+    // tile range land on the same XCD for every frame (the padding workgroups return at once).
+    const uint32_t gx = (a.ntiles + kWTiles - 1) / kWTiles;
+    const dim3 grid((gx + 7u) / 8u * 8u, nframes);
     if (a.wire)
-        hipLaunchKernelGGL(k_expand<true>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_expand<true>, grid, dim3(64), 0, s, a);
     else
-        hipLaunchKernelGGL(k_expand<false>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_expand<false>, grid, dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
