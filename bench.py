@@ -32,6 +32,16 @@ from cudavideostream_amd import gather as gx  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
+def metric_name(W, H):
+    """BASELINE.json's metric, verbatim for its 1080p configuration (same wording at other sizes)."""
+    name = "1920\u00d71080 RGB24 frames/sec (diff+threshold+pack); achieved HBM GB/s vs peak"
+    try:
+        name = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        pass
+    return name if (W, H) == (1920, 1080) else name.replace("1920\u00d71080", f"{W}\u00d7{H}")
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -204,7 +214,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": f"{W}x{H} RGB24 frames/sec (diff+threshold+pack); achieved HBM GB/s vs peak",
+            "metric": metric_name(W, H),
             "value": round(world * B * K / elapsed, 1),
             "unit": "frames/s",
             "n_gpus": world,
