@@ -116,7 +116,46 @@ def cpu_baseline(args, base, frames, dev):
                 "all_cores": {"value": round(done_mt / dt_mt, 2), "unit": "frames/s", "cores": nthr,
                               "host_cores": ncores,
                               "sample": f"{done_mt} frames, row-band pthreads, {dt_mt:.1f} s"}}
+    ref = reference_filter_chain(args, h_base, h_frames)
+    if ref:
+        base_obj["reference_filter_chain"] = ref
     return base_obj, bool(ok)
+
+
+def reference_filter_chain(args, h_base, h_frames, nframes=8):
+    """Part of the cpu_baseline leg: the reference's OWN CPU branch for the gray-avg -> histogram -> two-max ->
+    binarize chain (server/src/server.cpp:96-135, compiled unmodified into oracle/_ref/server_cpu where the
+    reference tree was present), timed by the reference's own per-frame `FOR:` counter (server.cpp:77,144,164)
+    on this host.  The GPU counterpart is the fused chain of tools/bench_filters.py (3.7 us per 1080p frame)."""
+    import re
+    import subprocess
+    import tempfile
+    from oracle import pyoracle as po
+    exe = po.ref_server_cpu_path()
+    if exe is None:
+        return None
+    T = min(nframes, h_frames.shape[0])
+    # the reference prints its counters once per second (server.cpp:151): loop the frames long enough
+    repeat = min(4000, max(2, int(1500 * (1920 * 1080) / (args.width * args.height) / T)))   # ~1500 1080p frames
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
+            with open(fin, "wb") as f:
+                f.write(np.array([args.width, args.height, T], np.int32).tobytes())
+                f.write(h_base.tobytes())
+                f.write(h_frames[:T].tobytes())
+            r = subprocess.run([exe], env=dict(os.environ, REF_IN=fin, REF_OUT=fout, REF_REPEAT=str(repeat)),
+                               check=True, stdout=subprocess.PIPE, timeout=120)
+    except Exception as e:  # a missing or foreign binary must not cost the bench line
+        return {"skipped": repr(e)[:120]}
+    ms = sorted(float(m) for m in re.findall(r"FOR:\s*([0-9.]+) ms", r.stdout.decode(errors="replace")))
+    if not ms:
+        return {"skipped": "no FOR: lines in the reference's output"}
+    med = ms[len(ms) // 2]
+    return {"value": round(1e3 / med, 1), "unit": "frames/s", "cores": 1, "kind": "reference",
+            "ms_per_frame_median": round(med, 3),
+            "sample": f"{T * repeat} frames through oracle/_ref/server_cpu (server.cpp CPU branch), "
+                      f"{len(ms)} readings of its own FOR: counter"}
 
 
 def main():

@@ -2,7 +2,7 @@
 """Soak run (not part of the test suite): thousands of small batches of random geometry and content through
 one long-lived core per geometry, every result compared with the oracle.  Meant to shake out rare ordering
 problems (the scan kernel's ticket, stream reuse) that a single pass of the parity tests would not meet.
-    python tools/soak.py [iterations]      exits non-zero on the first mismatch"""
+    python tests/soak.py [iterations]      exits non-zero on the first mismatch"""
 import os
 import sys
 

@@ -79,12 +79,14 @@ def test_no_cpu_fallback(built):
 
 def test_product_does_not_import_oracle():
     """The package must never reach into oracle/ (test infrastructure): no import, link or path."""
-    pkg = os.path.join(ROOT, "cudavideostream_amd")
     banned = re.compile(r"import\s+oracle|from\s+oracle|oracle/|liboracle|cpu_ref|pyoracle")
-    for dirpath, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp", ".cuh")) or f == "Makefile":
-                text = open(os.path.join(dirpath, f), errors="replace").read()
-                assert not banned.search(text), f"{os.path.join(dirpath, f)} references the oracle"
+    # the package, the C-ABI header and the measurement/example tools: only tests/, smoke() and bench.py's
+    # cpu_baseline leg may touch the oracle
+    for top in ("cudavideostream_amd", "include", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp", ".cuh", ".sh")) or f == "Makefile":
+                    text = open(os.path.join(dirpath, f), errors="replace").read()
+                    assert not banned.search(text), f"{os.path.join(dirpath, f)} references the oracle"
     out = subprocess.run(["ldd", lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out

@@ -14,7 +14,13 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cudavideostream_amd import CUDACore, lib, synth  # noqa: E402
-from oracle import pyoracle as po  # noqa: E402  (only for the Gaussian kernel values)
+
+
+def gaussian3(sigma):
+    """A normalised 3x3 Gaussian (symmetric, like the server's; the exact values do not matter for timing)."""
+    import numpy as np
+    g = np.exp(-(np.arange(-1, 2)[:, None] ** 2 + np.arange(-1, 2)[None, :] ** 2) / (2.0 * sigma * sigma))
+    return (g / g.sum()).astype(np.float32).reshape(-1)
 
 
 def main():
@@ -30,7 +36,7 @@ def main():
     _, frames = synth.webcam_stream(B + 1, W, H, device=dev)
     cur, prev = frames[1:], frames[:-1]
     out = torch.empty((B, n), dtype=torch.uint8, device=dev)
-    core = CUDACore(W, H, k=po.gaussian_kernel(3, 1.5), max_batch=B)
+    core = CUDACore(W, H, k=gaussian3(1.5), max_batch=B)
     core.use_torch_stream()
     N = float(n)
     ops = [
@@ -91,44 +97,6 @@ def main():
                           "batch": B, "changed_bytes_per_frame": round((int(d_off[B].item()) & 0xFFFFFFFF) / B, 1)}),
               flush=True)
     core.close()
-    cpu_reference_line(W, H)
-
-
-def cpu_reference_line(W, H, T=16, seconds=8.0):
-    """The reference's own CPU branch for the gray-avg -> histogram -> two-max -> binarize chain
-    (server/src/server.cpp:96-135, compiled unmodified into oracle/_ref/server_cpu), timed by the
-    reference's own per-frame `FOR:` counter (server.cpp:77,144,164) on this host, next to the GPU lines."""
-    import re
-    import subprocess
-    import tempfile
-
-    import numpy as np
-    exe = po.ref_server_cpu_path()
-    if exe is None:
-        print(json.dumps({"filter": "reference server.cpp CPU branch", "skipped": "oracle/_ref/server_cpu not built"}))
-        return
-    base, frames = synth.webcam_stream(T, W, H)
-    with tempfile.TemporaryDirectory() as tmp:
-        fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
-        with open(fin, "wb") as f:
-            f.write(np.array([W, H, T], np.int32).tobytes())
-            f.write(base.tobytes())
-            f.write(frames.tobytes())
-        # the reference prints its counters once per second (server.cpp:151): loop the sequence long enough
-        # for several prints (about 12 ms per 1080p frame sizes the repeat count)
-        repeat = max(2, int(seconds / (T * 0.012 * (W * H) / (1920 * 1080))))
-        r = subprocess.run([exe], env=dict(os.environ, REF_IN=fin, REF_OUT=fout, REF_REPEAT=str(repeat)),
-                           check=True, stdout=subprocess.PIPE, timeout=600)
-    ms = [float(m) for m in re.findall(r"FOR:\s*([0-9.]+) ms", r.stdout.decode(errors="replace"))]
-    if not ms:
-        print(json.dumps({"filter": "reference server.cpp CPU branch", "skipped": "no FOR: lines in its output"}))
-        return
-    ms.sort()
-    med = ms[len(ms) // 2]
-    print(json.dumps({"filter": "reference server.cpp CPU branch (gray avg + histogram + two-max + binarize)",
-                      "kind": "reference", "cores": 1, "ms_per_frame_median": round(med, 3),
-                      "frames_per_s": round(1e3 / med, 1), "samples": len(ms), "frames_processed": T * repeat,
-                      "timer": "the reference's own FOR: counter, server.cpp:164"}), flush=True)
 
 
 if __name__ == "__main__":
