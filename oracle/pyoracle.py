@@ -177,6 +177,14 @@ def conv3x3(img, w, h, k):
     return out
 
 
+def conv3x3_intacc(img, w, h, k):
+    """tests/noise_filter_benchmark/cpu.cu:72-98 on the frame widened to int (the reference's `int *y`)."""
+    i = np.ascontiguousarray(np.asarray(img, dtype=np.uint8).reshape(-1).astype(np.int32))
+    out = np.empty_like(i)
+    lib().ora_conv3x3_intacc(i, out, w, h, np.ascontiguousarray(k, dtype=np.float32))
+    return out
+
+
 def median5x5(img, w, h):
     img = _u8(img)
     out = np.empty_like(img)

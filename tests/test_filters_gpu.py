@@ -45,6 +45,26 @@ def test_gray_heat_red(po, w, h):
         assert np.array_equal(d_pad[1:].cpu().numpy(), po.gray_avg(img))
 
 
+def test_heat_map_spot_values_of_the_reference_expression():
+    """tests/heat_map_benchmark/cpu.cu:19-27 evaluated by hand, normaliser 510: the colour of
+    d = |dB|+|dG|+|dR| is (r,g,b) = d 0 -> (0,0,255), 1 -> (0,1,254), 255 -> (0,255,0), 510 -> (255,0,0),
+    600 -> (216,0,0), 765 -> (0,0,0) -- red falls off again above 510.  No oracle involved."""
+    spots = {0: (0, 0, 255), 1: (0, 1, 254), 255: (0, 255, 0), 510: (255, 0, 0), 600: (216, 0, 0), 765: (0, 0, 0)}
+    ds = sorted(spots)
+    cur = np.zeros((len(ds), 3), np.uint8)
+    for i, d in enumerate(ds):                  # spread d over the three channels of one pixel
+        cur[i] = (min(d, 255), min(max(d - 255, 0), 255), min(max(d - 510, 0), 255))
+    prv = np.zeros_like(cur)
+    with CUDACore(len(ds), 1) as core:
+        for a, b in ((cur, prv), (prv, cur)):   # |.| per channel: direction does not matter
+            d_o = dev_out(cur.size)
+            core.heat_map(to_dev(a.reshape(-1)), to_dev(b.reshape(-1)), d_o); core.synchronize()
+            out = d_o.cpu().numpy().reshape(-1, 3)
+            for i, d in enumerate(ds):
+                r, g, bl = spots[d]
+                assert tuple(out[i]) == (bl, g, r), (d, tuple(out[i]))     # stored B,G,R (cpu.cu:62-64)
+
+
 def test_gray_weighted_exhaustive_2_24(po):
     """Every (B, G, R) triple against the double expression of tests/grayscale-weighted/cpu.cu:40."""
     w, h = 4096, 4096

@@ -41,6 +41,73 @@ def test_cpu_branch_matches_reference_live(po, tmp_path):
         assert np.array_equal(mine, out[t])
 
 
+def test_f1f2_changed_byte_count_is_the_reports(po):
+    """The reference-held number for the hot path: f1.jpg vs f2.jpg differ in 369350 bytes at threshold 20
+    (REPORT/report.tex:2594; counted by tests/noise_filter_benchmark/v2.cu:106-114,215).  Pins the oracle's
+    strict comparison: `>=` would give 413893."""
+    g = golden("ref_f1f2_1080p.npz")
+    f1, f2 = g["f1"].reshape(-1), g["f2"].reshape(-1)
+    want = int(g["count_gt20"])
+    assert want == 369350
+    for cur, prev in ((f2, f1), (f1, f2)):      # abs() is symmetric: both orders count the same bytes
+        c, xs, df, st = po.diff_pack(cur, prev)
+        assert c == want
+        assert c != int(g["count_ge20"])
+        # the entries are exactly the bytes getCountDifference counts, ascending (test.cu:563-573)
+        flagged = np.flatnonzero(np.abs(cur.astype(np.int32) - prev.astype(np.int32)) > 20)
+        assert np.array_equal(xs, flagged)
+        assert np.array_equal(df, (cur[flagged].astype(np.int32) - prev[flagged]).astype(np.uint8))
+        assert np.array_equal(st[flagged], cur[flagged])
+        keep = np.ones(cur.size, bool); keep[flagged] = False
+        assert np.array_equal(st[keep], prev[keep])
+    # one threshold step either side moves the count: the comparison constant is pinned too
+    assert po.diff_pack(f2, f1, thr=19)[0] == int(g["count_ge20"])
+    assert po.diff_pack(f2, f1, thr=21)[0] < want
+    # the row-band form used as the all-cores baseline counts the same
+    assert po.diff_pack_mt(f2, f1, nthreads=8)[0] == want
+
+
+def test_f1f2_red_map_marks_the_pixels_owning_those_bytes(po):
+    """tests/heat_map_red_benchmark/cpu.cu:38-55 on the report's frame pair: a pixel is red iff it owns at
+    least one of the 369350 counted bytes."""
+    g = golden("ref_f1f2_1080p.npz")
+    f1, f2 = g["f1"].reshape(-1), g["f2"].reshape(-1)
+    _, xs, _, _ = po.diff_pack(f2, f1)
+    red = po.red_dense(f2, f1).reshape(-1, 3)
+    owners = np.zeros(f1.size // 3, bool)
+    owners[xs // 3] = True
+    assert np.array_equal(red[:, 2] == 255, owners)
+    assert not red[:, :2].any() and set(np.unique(red[:, 2])) <= {0, 255}
+    # the overlap form paints the same pixels onto the previous frame (kernels.cu:273-281)
+    over = po.red_overlap(f1, xs).reshape(-1, 3)
+    assert np.array_equal(over[owners, 2], np.full(int(owners.sum()), 255, np.uint8))
+    assert np.array_equal(over[~owners], f1.reshape(-1, 3)[~owners])
+
+
+def test_f1f2_filter_table(po):
+    """REPORT/report.tex:2601-2611: share of bytes still changed after both frames went through the K x K
+    filter -- mean K=3 3.37 %, Gaussian K=3 sigma=1 3.58 %.  The oracle's float-accumulator filter
+    (kernels.cu:97-136 semantics) leaves 3.35 / 3.56 %, the reference's int-accumulator CPU statement
+    (cpu.cu:72-98) 3.39 / 3.59 %: the report's figures lie between the two, all agree to two digits."""
+    g = golden("ref_f1f2_1080p.npz")
+    f1, f2 = g["f1"], g["f2"]
+    n = f1.size
+    for name, k in (("mean3", np.full(9, np.float32(1.0 / 9), np.float32)), ("gauss3_s1", po.gaussian_kernel(3, 1.0))):
+        a, b = po.conv3x3(f1, 1920, 1080, k), po.conv3x3(f2, 1920, 1080, k)
+        resid = po.diff_pack(b, a)[0]
+        assert resid == int(g["resid_" + name])
+        report = float(g["report_pct_" + name])
+        assert abs(100.0 * resid / n - report) < 0.05
+        ia = po.conv3x3_intacc(f1, 1920, 1080, k)
+        d = a.astype(np.int32) - ia
+        assert d.min() >= 0 and d.max() <= 8        # nine truncations of < 1 each (cpu.cu:82)
+        ib = po.conv3x3_intacc(f2, 1920, 1080, k)
+        resid_i = int((np.abs(ia - ib) > 20).sum())
+        assert resid_i == int(g["resid_intacc_" + name])
+        assert abs(100.0 * resid_i / n - report) < 0.05
+        assert 100.0 * resid / n <= report <= 100.0 * resid_i / n
+
+
 def test_two_max_dead_branch(po):
     """server.cpp:116 `else if` can never fire (sec_max == max after every record)."""
     rng = np.random.default_rng(3)

@@ -1,0 +1,88 @@
+"""GPU parity against the one number the reference holds for the hot path: its two 1080p test photographs
+(tests/noise_filter_benchmark/f1.jpg, f2.jpg) differ in 369350 bytes at threshold 20 (REPORT/report.tex:2594,
+counted by v2.cu:106-114,215), and after the K=3 filters in 3.37 % / 3.58 % of the bytes
+(report.tex:2601-2611).  Fixture: tests/golden/ref_f1f2_1080p.npz (tests/golden/make_ref_f1f2.py).
+Everything goes through the C-ABI; the oracle is only the checker."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from gpu_util import DEV, CUDACore, run_stream, to_dev  # noqa: E402
+
+W, H = 1920, 1080
+
+
+@pytest.fixture(scope="module")
+def pair():
+    g = golden("ref_f1f2_1080p.npz")
+    return g, np.ascontiguousarray(g["f1"].reshape(-1)), np.ascontiguousarray(g["f2"].reshape(-1))
+
+
+def test_pair_mode_counts_369350(po, pair):
+    g, f1, f2 = pair
+    with CUDACore(W, H, max_batch=2) as core:
+        # both orders in one batch: |a - b| is symmetric, the entries are not
+        cur, prev = np.stack([f2, f1]), np.stack([f1, f2])
+        off, xs, df, _ = run_stream(core, cur, pair_prev=prev)
+        assert int(off[1]) == 369350 == int(g["count_gt20"]) and int(off[2]) == 2 * 369350
+        assert int(off[1]) != int(g["count_ge20"])
+        for t in range(2):
+            c, exs, edf, _ = po.diff_pack(cur[t], prev[t])
+            assert np.array_equal(xs[off[t]:off[t + 1]], exs) and np.array_equal(df[off[t]:off[t + 1]], edf)
+
+
+@pytest.mark.parametrize("thr,key", [(20, "count_gt20"), (19, "count_ge20")])
+def test_stream_mode_counts_369350(po, pair, thr, key):
+    """f1 as the client's frame, f2 arriving: count, entries and the fed-back state."""
+    g, f1, f2 = pair
+    with CUDACore(W, H, max_batch=1, threshold=thr) as core:
+        core.set_state(f1)
+        off, xs, df, _ = run_stream(core, f2[None, :])
+        assert int(off[1]) == int(g[key])
+        c, exs, edf, est = po.diff_pack(f2, f1, thr)
+        assert np.array_equal(xs, exs) and np.array_equal(df, edf)
+        assert np.array_equal(core.get_state(), est)
+
+
+def test_red_maps_flag_the_owning_pixels(po, pair):
+    g, f1, f2 = pair
+    owners = np.zeros(f1.size // 3, bool)
+    owners[np.flatnonzero(np.abs(f2.astype(np.int32) - f1.astype(np.int32)) > 20) // 3] = True
+    with CUDACore(W, H, max_batch=1) as core:
+        d_o = torch.full((f1.size,), 0x5A, dtype=torch.uint8, device=DEV)
+        core.red_dense(to_dev(f2), to_dev(f1), d_o); core.synchronize()
+        red = d_o.cpu().numpy()
+        assert np.array_equal(red, po.red_dense(f2, f1))
+        assert np.array_equal(red.reshape(-1, 3)[:, 2] == 255, owners)
+        # the packed stream of the same pair paints the same pixels (kernels.cu:513-518)
+        core.set_state(f1)
+        off, xs, df, (d_xs, _) = run_stream(core, f2[None, :])
+        d_img = to_dev(f1)
+        core.red_overlap(d_img, d_xs, None, int(off[1])); core.synchronize()
+        over = d_img.cpu().numpy().reshape(-1, 3)
+        assert np.array_equal(over[:, 2] == 255, owners | (f1.reshape(-1, 3)[:, 2] == 255))
+        assert np.array_equal(over, po.red_overlap(f1, xs).reshape(-1, 3))
+
+
+@pytest.mark.parametrize("name", ["mean3", "gauss3_s1"])
+def test_filter_table(po, pair, name):
+    """Noise filter on both frames, then diff+threshold+pack of the filtered pair: the count is the oracle's
+    and agrees with the report's table to two digits."""
+    g, f1, f2 = pair
+    k = np.full(9, np.float32(1.0 / 9), np.float32) if name == "mean3" else po.gaussian_kernel(3, 1.0)
+    with CUDACore(W, H, max_batch=1, k=k) as core:
+        d_a = torch.empty(f1.size, dtype=torch.uint8, device=DEV)
+        d_b = torch.empty(f1.size, dtype=torch.uint8, device=DEV)
+        core.conv3x3(to_dev(f1), d_a)
+        core.conv3x3(to_dev(f2), d_b)
+        core.synchronize()
+        assert np.array_equal(d_a.cpu().numpy(), po.conv3x3(f1, W, H, k))
+        assert np.array_equal(d_b.cpu().numpy(), po.conv3x3(f2, W, H, k))
+        off, xs, df, _ = run_stream(core, d_b[None, :], pair_prev=d_a[None, :])
+        resid = int(off[1])
+    assert resid == int(g["resid_" + name])
+    assert abs(100.0 * resid / f1.size - float(g["report_pct_" + name])) < 0.05
