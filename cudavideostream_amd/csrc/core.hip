@@ -57,6 +57,15 @@ struct mi355_core {
     uint4 *rec = nullptr, *meta = nullptr;
     uint32_t *groff = nullptr, *totals = nullptr;
     uint32_t *offsets = nullptr;  // T+1, used by exec()
+    // one-kernel stream form (diff_fused.hip, opt-in experiment); fused == false: not asked for, or the frame does not fit
+    bool fused = false;
+    uint32_t nwg = 0, fgroups = 0;
+    uint32_t *f_wgsum = nullptr, *f_sync = nullptr, *f_ovf = nullptr;   // f_sync = {status[16], arrive[E], garrive[E*G], gsum[T*G]}; f_ready: a line per workgroup
+    uint32_t *f_ready = nullptr;
+    uint32_t f_tag = 0;            // launch tag of the wgsum and ready words, 1..65535
+    uint4 *f_spill = nullptr;
+    size_t f_sync_words = 0;
+    uint32_t *h_status = nullptr;  // pinned copy of the fused kernel's status word
     int32_t *one_xs = nullptr;
     uint8_t *one_diff = nullptr;
     int32_t *hist = nullptr, *thr = nullptr;
@@ -142,6 +151,73 @@ void build_heat_lut(uint8_t *lut) {
     }
 }
 
+// The one-kernel stream form needs every workgroup resident at once: decided here, once per core.
+int setup_fused(mi355_core *c) {
+    c->fused = false;
+    const char *env = getenv("MI355_FUSED");
+    if (!(c->cfg.flags & MI355_FLAG_FUSED) && !(env && env[0] == '1')) return MI355_OK;   // opt-in experiment
+    if (c->n == 0 || c->n % 16u) return MI355_OK;
+    c->nwg = (c->ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    c->fgroups = fused_groups(c->nwg);
+    const uint32_t cap = fused_capacity(c->device);
+    // workgroups are dealt to the 8 XCDs round-robin: each XCD must hold its share
+    const uint32_t per_xcd = (c->nwg + 7u) / 8u;
+    if (cap == 0 || per_xcd > cap / 8u || c->fgroups > 64u) return MI355_OK;
+    const size_t T = (size_t)c->cfg.max_batch;
+    c->f_sync_words = 16 + (size_t)fused_epochs((int)T) * (1 + c->fgroups) + T * c->fgroups;
+    if (int rc = dev_alloc(c, &c->f_ready, fused_ready_words(c->nwg))) return rc;
+    HIP_TRY(hipMemset(c->f_ready, 0, sizeof(uint32_t) * fused_ready_words(c->nwg)));
+    if (int rc = dev_alloc(c, &c->f_wgsum, T * c->nwg)) return rc;
+    HIP_TRY(hipMemset(c->f_wgsum, 0, sizeof(uint32_t) * T * c->nwg));
+    if (int rc = dev_alloc(c, &c->f_sync, c->f_sync_words)) return rc;
+    if (int rc = dev_alloc(c, &c->f_spill, fused_spill_records(c->ntiles))) return rc;
+    if (int rc = dev_alloc(c, &c->f_ovf, fused_ovf_entries(c->ntiles))) return rc;
+    HIP_TRY(hipHostMalloc((void **)&c->h_status, sizeof(uint32_t), hipHostMallocDefault));
+    *c->h_status = 0;
+    c->fused = true;
+    return MI355_OK;
+}
+
+int run_fused(mi355_core *c, const void *d_cur, size_t stride, int nframes, void *d_offsets, void *d_xs,
+              void *d_diff, size_t capacity) {
+    FusedArgs f{};
+    f.cur = (const uint8_t *)d_cur;
+    f.state = c->state;
+    f.stride = stride;
+    f.n = c->n;
+    f.nframes = nframes;
+    f.thr = c->cfg.threshold;
+    f.ntiles = c->ntiles;
+    f.nwg = c->nwg;
+    f.ngroups = c->fgroups;
+    f.wgsum = c->f_wgsum;
+    if (++c->f_tag > 0xffffu) {   // tags wrap: forget the words of 65535 launches ago
+        c->f_tag = 1;
+        HIP_TRY(hipMemsetAsync(c->f_wgsum, 0, sizeof(uint32_t) * (size_t)c->cfg.max_batch * c->nwg, c->stream));
+        HIP_TRY(hipMemsetAsync(c->f_ready, 0, sizeof(uint32_t) * fused_ready_words(c->nwg), c->stream));
+    }
+    const size_t E = fused_epochs(nframes);
+    f.tag = c->f_tag;
+    f.status = c->f_sync;
+    f.arrive = c->f_sync + 16;
+    f.garrive = f.arrive + E;
+    f.gsum = f.garrive + E * c->fgroups;
+    f.ready = c->f_ready;
+    f.offsets = (uint32_t *)d_offsets;
+    f.out_xs = (int32_t *)d_xs;
+    f.out_diff = (uint8_t *)d_diff;
+    f.capacity = capacity;
+    f.spill = c->f_spill;
+    f.ovf = c->f_ovf;
+    const size_t words = 16 + E * (1 + c->fgroups) + (size_t)nframes * c->fgroups;
+    HIP_TRY(hipMemsetAsync(c->f_sync, 0, words * sizeof(uint32_t), c->stream));
+    HIP_TRY(launch_diff_fused(f, c->stream));
+    // a bounded wait that expired leaves the outputs undefined: the status word travels to the host with
+    // the stream and is looked at by mi355_synchronize
+    HIP_TRY(hipMemcpyAsync(c->h_status, c->f_sync, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    return MI355_OK;
+}
+
 // d_wire != nullptr: the expander writes the sender's byte stream (capacity in bytes) instead of d_xs/d_diff.
 int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, size_t stride,
               int nframes, void *d_offsets, void *d_xs, void *d_diff, size_t capacity,
@@ -168,6 +244,15 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
         if (int rc = harvest_timing(c, mi355_core::kEvRing - 1)) return rc;
         tev = c->ev[(c->ev_head + c->ev_count) % mi355_core::kEvRing];
         HIP_TRY(hipEventRecord(tev[0], c->stream));
+    }
+    if (c->fused && !pair && !d_wire && (((uintptr_t)d_cur | stride) & 15u) == 0) {
+        if (int rc = run_fused(c, d_cur, stride, nframes, d_offsets, d_xs, d_diff, capacity)) return rc;
+        if (tev) {
+            HIP_TRY(hipEventRecord(tev[1], c->stream));
+            HIP_TRY(hipEventRecord(tev[2], c->stream));
+            c->ev_count += 1;
+        }
+        return MI355_OK;
     }
     PackArgs a{};
     a.cur = (const uint8_t *)d_cur;
@@ -251,6 +336,7 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (!rc) rc = dev_alloc(c, &c->totals, T + 1);   // + the scan kernel's ticket counter
     if (!rc) { e = hipMemset(c->totals, 0, (T + 1) * sizeof(uint32_t)); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipMemset", e); }
     if (!rc) rc = dev_alloc(c, &c->offsets, T + 1);
+    if (!rc) rc = setup_fused(c);
     if (!rc) rc = dev_alloc(c, &c->one_xs, N + 4);
     if (!rc) rc = dev_alloc(c, &c->one_diff, N + 16);
     if (!rc) rc = dev_alloc(c, &c->hist, 256 * T);
@@ -276,9 +362,10 @@ void mi355_destroy(mi355_core *c) {
     if (c->nslots) (void)mi355_pipe_close(c);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->meta, c->groff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
-                    c->lut, c->glyphs};
+                    c->lut, c->glyphs, c->f_wgsum, c->f_sync, c->f_spill, c->f_ovf, c->f_ready};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_count) (void)hipHostFree(c->h_count);
+    if (c->h_status) (void)hipHostFree(c->h_status);
     for (auto &slot : c->ev) for (auto &ev : slot) if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -307,6 +394,12 @@ int mi355_synchronize(mi355_core *c) {
     if (!c) return fail(MI355_ERR_INVALID, "null core");
     if (int rc = use_device(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->h_status && *c->h_status) {
+        *c->h_status = 0;
+        c->fused = false;   // the log path needs no co-residency
+        return fail(MI355_ERR_STATE, "fused diff kernel: a workgroup waited too long for the others (GPU shared?); "
+                                     "the batch's output and the state are undefined, the core now uses the log path");
+    }
     return MI355_OK;
 }
 

@@ -38,6 +38,39 @@ struct ExpandArgs {
     size_t capacity;          // entries of out_xs/out_diff, or bytes of wire
 };
 
+// The one-kernel stream form (diff_fused.hip).  sync words are zeroed before every launch.
+struct FusedArgs {
+    const uint8_t *cur;
+    uint8_t *state;
+    size_t stride;
+    uint32_t n;            // bytes per frame, a multiple of 16
+    int32_t nframes;
+    int32_t thr;
+    uint32_t ntiles;       // W
+    uint32_t nwg;          // workgroups that own tiles = ceil(W / 4)
+    uint32_t ngroups;      // ceil(nwg / 64) <= 64
+    uint32_t tag;          // 1..65535, different for consecutive launches
+    uint32_t *wgsum;       // [T][nwg]     flagged bytes of a workgroup's tiles per frame | tag << 16
+    uint32_t *gsum;        // [T][ngroups] the same added up per group of 64 workgroups | contributors << 20 (zeroed)
+    uint32_t *garrive;     // [ceil(T/8)][ngroups] workgroups of the group that have published the epoch (zeroed)
+    uint32_t *arrive;      // [ceil(T/8)]  groups that are complete                       (zeroed)
+    uint32_t *ready;       // [nwg][32]    per workgroup, own line: tag << 16 | epochs everybody has published
+    uint32_t *status;      // [1]          != 0: a bounded wait expired                  (zeroed)
+    uint32_t *offsets;     // [T+1] out
+    int32_t *out_xs;
+    uint8_t *out_diff;
+    size_t capacity;
+    uint4 *spill;          // [W][16][64] raw records of dense frames
+    uint32_t *ovf;         // [W][2][kOvf] FIFO entries beyond the LDS capacity
+};
+uint32_t fused_groups(uint32_t nwg);
+size_t fused_spill_records(uint32_t ntiles);
+size_t fused_ovf_entries(uint32_t ntiles);
+uint32_t fused_epochs(int nframes);
+size_t fused_ready_words(uint32_t nwg);
+uint32_t fused_capacity(int device);
+hipError_t launch_diff_fused(const FusedArgs &a, hipStream_t s);
+
 // diff_pack.hip
 hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, hipStream_t s);
 uint32_t expand_groups(uint32_t ntiles);

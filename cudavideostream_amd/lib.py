@@ -21,6 +21,9 @@ VIS_NONE, VIS_HEAT, VIS_RED, VIS_RED_OVERLAP, VIS_GRAY, VIS_BINARIZE = range(6)
  OP_RED_DENSE, OP_CONV3X3, OP_MEDIAN5X5) = range(1, 10)
 
 
+FLAG_FUSED = 1   # MI355_FLAG_FUSED: the one-kernel stream form (experiment, csrc/diff_fused.hip)
+
+
 class Config(C.Structure):
     _fields_ = [
         ("width", C.c_int32),
@@ -30,7 +33,7 @@ class Config(C.Structure):
         ("device", C.c_int32),
         ("noise_filter", C.c_int32),
         ("visualizer", C.c_int32),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32),
     ]
 
 

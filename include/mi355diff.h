@@ -51,8 +51,13 @@ typedef struct mi355_config {
     int32_t device;     /* HIP device ordinal, or -1 for the current device */
     int32_t noise_filter; /* != 0: exec() runs the 3x3 convolution first (NOISE_FILTER, common.h:5) */
     int32_t visualizer; /* MI355_VIS_* used by exec() (NOISE_VISUALIZER, common.h:11) */
-    int32_t reserved;
+    int32_t flags;      /* MI355_FLAG_*; 0 = defaults */
 } mi355_config;
+
+/* Experiment, off by default: mi355_diff_stream_batch as ONE resident kernel instead of the three-kernel log
+ * path, when the frame fits the device (every workgroup must be resident at once; 1080p fits).  Bit-exact with
+ * the log path and slower on the MI355X (csrc/diff_fused.hip says why).  Also MI355_FUSED=1 in the environment. */
+#define MI355_FLAG_FUSED 1
 
 /* ---- life cycle: CUDACore::CUDACore (kernels.cu:377-428) without the uploads ------------------ */
 int mi355_create(const mi355_config *cfg, mi355_core **out);

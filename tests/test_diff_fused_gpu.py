@@ -1,0 +1,103 @@
+"""GPU parity of the opt-in one-kernel stream form (csrc/diff_fused.hip, MI355_FLAG_FUSED) against the CPU
+oracle (tests/cuda_streaming/test.cu:560-576 restated): the same cases as the log path, bit-exact, through
+the C-ABI.  The experiment is not the product path; these tests keep it honest."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from cudavideostream_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from gpu_util import DEV, CUDACore, run_stream  # noqa: E402
+
+
+def check(po, core, base, frames, thr=20, **kw):
+    core.set_state(base)
+    off, xs, df, _ = run_stream(core, frames, **kw)
+    eo, exs, edf, est = po.diff_stream(np.asarray(frames), base, thr)
+    assert np.array_equal(off, eo), (off, eo)
+    assert np.array_equal(xs, exs) and np.array_equal(df, edf)
+    assert np.array_equal(core.get_state(), est)
+    return off
+
+
+def test_golden_stream_64x48():
+    g = golden("oracle_diff_stream_64x48.npz")
+    with CUDACore(64, 48, max_batch=8, fused=True) as core:
+        core.set_state(g["base"])
+        off, xs, df, _ = run_stream(core, g["frames"])
+        assert np.array_equal(off, g["offsets"]) and np.array_equal(xs, g["xs"])
+        assert np.array_equal(df, g["diff"]) and np.array_equal(core.get_state(), g["state"])
+
+
+@pytest.mark.parametrize("T", [1, 2, 7, 8, 9, 16, 17, 25])
+def test_batch_lengths_across_epochs(po, T):
+    """Epochs of 8 frames: every tail length, one to several epochs; 80x60 has a partial last tile."""
+    base, frames = synth.webcam_stream(T, 80, 60, seed=T)
+    with CUDACore(80, 60, max_batch=25, fused=True) as core:
+        check(po, core, base, frames)
+
+
+def test_every_byte_pair_and_thresholds(po):
+    cur, prev = synth.edge_strip(3)
+    for thr in (0, 20, 127):
+        with CUDACore(256, 256, threshold=thr, max_batch=1, fused=True) as core:
+            check(po, core, prev, cur[None, :], thr=thr)
+
+
+def test_dense_frames_take_the_raw_path(po):
+    n = 3 * 128 * 64
+    with CUDACore(128, 64, max_batch=12, fused=True) as core:
+        cur, prev = synth.flip_pair(n)
+        assert check(po, core, prev, cur[None, :])[1] == n                   # every byte: arithmetic fast path
+        frames = np.stack([synth.refrand_frame(n, 30 + t) for t in range(12)])  # S0-dense, more than one epoch
+        check(po, core, synth.refrand_frame(n, 7), frames)
+        cur, prev = synth.static_pair(n)
+        assert check(po, core, prev, cur[None, :])[1] == 0
+
+
+def test_fifo_overflow_path(po):
+    """Up to 32 candidate lanes per frame and tile with 16 flagged bytes each stay on the staged path: 8 frames
+    of that are 4096 entries per tile, far beyond the 384 the LDS FIFO holds."""
+    w, h, T = 128, 64, 9
+    n = 3 * w * h
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 100, n, dtype=np.uint8)
+    frames = np.repeat(base[None, :], T, axis=0).copy()
+    for t in range(T):
+        for tile in range(n // 1024):
+            lanes = rng.choice(64, size=int(rng.integers(20, 33)), replace=False)
+            for ln in lanes:
+                o = tile * 1024 + ln * 16
+                frames[t, o:o + 16] = base[o:o + 16] + 100 + (t % 2) * 50
+    with CUDACore(w, h, max_batch=T, fused=True) as core:
+        check(po, core, base, frames)
+
+
+def test_capacity_truncation_and_consecutive_batches(po):
+    base, frames = synth.webcam_stream(11, 64, 48, seed=8)
+    eo, exs, edf, est = po.diff_stream(frames, base)
+    with CUDACore(64, 48, max_batch=11, fused=True) as core:
+        core.set_state(base)
+        cap = int(eo[2]) + 5
+        off, xs, df, _ = run_stream(core, frames, capacity=cap)
+        assert np.array_equal(off, eo) and np.array_equal(xs, exs[:cap]) and np.array_equal(df, edf[:cap])
+        core.set_state(base)
+        o1, x1, d1, _ = run_stream(core, frames[:6])
+        o2, x2, d2, _ = run_stream(core, frames[6:])
+        assert np.array_equal(np.concatenate([x1, x2]), exs) and np.array_equal(np.concatenate([d1, d2]), edf)
+        assert np.array_equal(np.concatenate([o1, o2[1:] + o1[-1]]), eo)
+        assert np.array_equal(core.get_state(), est)
+
+
+def test_1080p_stream_and_reference_count(po):
+    W, H, T = 1920, 1080, 10
+    base, frames = synth.webcam_stream(T, W, H, device=DEV)
+    with CUDACore(W, H, max_batch=T, fused=True) as core:
+        check(po, core, base.cpu().numpy(), frames.cpu().numpy())
+        g = golden("ref_f1f2_1080p.npz")      # REPORT/report.tex:2594
+        core.set_state(np.ascontiguousarray(g["f1"].reshape(-1)))
+        off, xs, df, _ = run_stream(core, np.ascontiguousarray(g["f2"].reshape(1, -1)))
+        assert int(off[1]) == 369350 == int(g["count_gt20"])

@@ -87,6 +87,7 @@ def test_random_filters(po, seed):
 
         def run(fn, *args):
             d_o = torch.full((n + 16,), 0x3C, dtype=torch.uint8, device=DEV)
+            torch.cuda.synchronize()    # the fill runs on torch's stream, the core on its own
             fn(*args, d_o)
             core.synchronize()
             got = d_o.cpu().numpy()
