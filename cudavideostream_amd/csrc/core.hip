@@ -66,6 +66,12 @@ struct mi355_core {
     uint4 *f_spill = nullptr;
     size_t f_sync_words = 0;
     uint32_t *h_status = nullptr;  // pinned copy of the fused kernel's status word
+    // one-pass pair form (diff_chain.hip)
+    bool chain = false;
+    uint32_t cgroups = 0, c_tag = 0, c_resident = 0;
+    uint64_t *c_desc = nullptr;    // [T][cgroups] then [T] frame totals
+    uint32_t *c_status = nullptr;  // device word
+    uint32_t *h_cstatus = nullptr; // pinned copy
     int32_t *one_xs = nullptr;
     uint8_t *one_diff = nullptr;
     int32_t *hist = nullptr, *thr = nullptr;
@@ -178,6 +184,56 @@ int setup_fused(mi355_core *c) {
     return MI355_OK;
 }
 
+// Experiment, opt-in (MI355_FLAG_CHAIN or MI355_CHAIN=1): the pair form as one chained-scan pass
+// (diff_chain.hip), when the frame bytes are a multiple of 16.
+int setup_chain(mi355_core *c) {
+    c->chain = false;
+    const char *env = getenv("MI355_CHAIN");
+    if (!(c->cfg.flags & MI355_FLAG_CHAIN) && !(env && env[0] == '1')) return MI355_OK;
+    if (c->n == 0 || c->n % 16u) return MI355_OK;
+    c->cgroups = chain_groups(c->ntiles);
+    c->c_resident = chain_capacity(c->device);
+    if (c->c_resident == 0) return MI355_OK;
+    const size_t T = (size_t)c->cfg.max_batch, words = T * c->cgroups + T;
+    if (int rc = dev_alloc(c, &c->c_desc, words)) return rc;
+    HIP_TRY(hipMemset(c->c_desc, 0, words * sizeof(uint64_t)));
+    if (int rc = dev_alloc(c, &c->c_status, 16)) return rc;
+    HIP_TRY(hipMemset(c->c_status, 0, 16 * sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc((void **)&c->h_cstatus, sizeof(uint32_t), hipHostMallocDefault));
+    *c->h_cstatus = 0;
+    c->chain = true;
+    return MI355_OK;
+}
+
+int run_chain(mi355_core *c, const void *d_cur, const void *d_prev, size_t stride, int nframes, void *d_offsets,
+              void *d_xs, void *d_diff, size_t capacity) {
+    const size_t T = (size_t)c->cfg.max_batch;
+    if (++c->c_tag > 0xffffu) {   // tags wrap: forget the descriptors of 65535 launches ago
+        c->c_tag = 1;
+        HIP_TRY(hipMemsetAsync(c->c_desc, 0, (T * c->cgroups + T) * sizeof(uint64_t), c->stream));
+    }
+    ChainArgs a{};
+    a.cur = (const uint8_t *)d_cur;
+    a.prev = (const uint8_t *)d_prev;
+    a.stride = stride;
+    a.n = c->n;
+    a.nframes = nframes;
+    a.thr = c->cfg.threshold;
+    a.ntiles = c->ntiles;
+    a.ngroups = c->cgroups;
+    a.tag = c->c_tag;
+    a.desc = c->c_desc;
+    a.fdesc = c->c_desc + T * c->cgroups;
+    a.status = c->c_status;
+    a.offsets = (uint32_t *)d_offsets;
+    a.out_xs = (int32_t *)d_xs;
+    a.out_diff = (uint8_t *)d_diff;
+    a.capacity = capacity;
+    HIP_TRY(launch_diff_chain(a, c->c_resident, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_cstatus, c->c_status, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    return MI355_OK;
+}
+
 int run_fused(mi355_core *c, const void *d_cur, size_t stride, int nframes, void *d_offsets, void *d_xs,
               void *d_diff, size_t capacity) {
     FusedArgs f{};
@@ -247,6 +303,15 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     }
     if (c->fused && !pair && !d_wire && (((uintptr_t)d_cur | stride) & 15u) == 0) {
         if (int rc = run_fused(c, d_cur, stride, nframes, d_offsets, d_xs, d_diff, capacity)) return rc;
+        if (tev) {
+            HIP_TRY(hipEventRecord(tev[1], c->stream));
+            HIP_TRY(hipEventRecord(tev[2], c->stream));
+            c->ev_count += 1;
+        }
+        return MI355_OK;
+    }
+    if (c->chain && pair && !d_wire && (((uintptr_t)d_cur | (uintptr_t)d_prev | stride) & 15u) == 0) {
+        if (int rc = run_chain(c, d_cur, d_prev, stride, nframes, d_offsets, d_xs, d_diff, capacity)) return rc;
         if (tev) {
             HIP_TRY(hipEventRecord(tev[1], c->stream));
             HIP_TRY(hipEventRecord(tev[2], c->stream));
@@ -337,6 +402,7 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (!rc) { e = hipMemset(c->totals, 0, (T + 1) * sizeof(uint32_t)); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipMemset", e); }
     if (!rc) rc = dev_alloc(c, &c->offsets, T + 1);
     if (!rc) rc = setup_fused(c);
+    if (!rc) rc = setup_chain(c);
     if (!rc) rc = dev_alloc(c, &c->one_xs, N + 4);
     if (!rc) rc = dev_alloc(c, &c->one_diff, N + 16);
     if (!rc) rc = dev_alloc(c, &c->hist, 256 * T);
@@ -362,10 +428,11 @@ void mi355_destroy(mi355_core *c) {
     if (c->nslots) (void)mi355_pipe_close(c);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->meta, c->groff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
-                    c->lut, c->glyphs, c->f_wgsum, c->f_sync, c->f_spill, c->f_ovf, c->f_ready};
+                    c->lut, c->glyphs, c->f_wgsum, c->f_sync, c->f_spill, c->f_ovf, c->f_ready, c->c_desc, c->c_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_count) (void)hipHostFree(c->h_count);
     if (c->h_status) (void)hipHostFree(c->h_status);
+    if (c->h_cstatus) (void)hipHostFree(c->h_cstatus);
     for (auto &slot : c->ev) for (auto &ev : slot) if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -394,6 +461,13 @@ int mi355_synchronize(mi355_core *c) {
     if (!c) return fail(MI355_ERR_INVALID, "null core");
     if (int rc = use_device(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->h_cstatus && *c->h_cstatus) {
+        *c->h_cstatus = 0;
+        (void)hipMemsetAsync(c->c_status, 0, sizeof(uint32_t), c->stream);
+        c->chain = false;   // the log path waits for nothing
+        return fail(MI355_ERR_STATE, "chained pair kernel: a block waited too long for its predecessors; the batch's "
+                                     "output is undefined, the core now uses the log path");
+    }
     if (c->h_status && *c->h_status) {
         *c->h_status = 0;
         c->fused = false;   // the log path needs no co-residency

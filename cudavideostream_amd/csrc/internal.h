@@ -71,6 +71,28 @@ size_t fused_ready_words(uint32_t nwg);
 uint32_t fused_capacity(int device);
 hipError_t launch_diff_fused(const FusedArgs &a, hipStream_t s);
 
+// The one-pass pair form (diff_chain.hip): chained scan, descriptors tagged per launch.
+struct ChainArgs {
+    const uint8_t *cur, *prev;
+    size_t stride;
+    uint32_t n;            // bytes per frame, a multiple of 16
+    int32_t nframes;
+    int32_t thr;
+    uint32_t ntiles;       // W
+    uint32_t ngroups;      // blocks (64 tiles) per frame
+    uint32_t tag;          // 1..65535, different for consecutive launches
+    uint64_t *desc;        // [T][ngroups] value | tag << 32 | state << 48 (1 aggregate, 2 inclusive prefix in the frame)
+    uint64_t *fdesc;       // [T]          entries of frames 0..t | tag << 32 | 2 << 48
+    uint32_t *status;      // [1]          != 0: a bounded wait expired (zeroed)
+    uint32_t *offsets;     // [T+1] out
+    int32_t *out_xs;
+    uint8_t *out_diff;
+    size_t capacity;
+};
+uint32_t chain_groups(uint32_t ntiles);
+uint32_t chain_capacity(int device);
+hipError_t launch_diff_chain(const ChainArgs &a, uint32_t resident_workgroups, hipStream_t s);
+
 // diff_pack.hip
 hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, hipStream_t s);
 uint32_t expand_groups(uint32_t ntiles);

@@ -22,6 +22,7 @@ VIS_NONE, VIS_HEAT, VIS_RED, VIS_RED_OVERLAP, VIS_GRAY, VIS_BINARIZE = range(6)
 
 
 FLAG_FUSED = 1   # MI355_FLAG_FUSED: the one-kernel stream form (experiment, csrc/diff_fused.hip)
+FLAG_CHAIN = 2   # MI355_FLAG_CHAIN: the one-pass chained-scan pair form (experiment, csrc/diff_chain.hip)
 
 
 class Config(C.Structure):

@@ -58,6 +58,10 @@ typedef struct mi355_config {
  * path, when the frame fits the device (every workgroup must be resident at once; 1080p fits).  Bit-exact with
  * the log path and slower on the MI355X (csrc/diff_fused.hip says why).  Also MI355_FUSED=1 in the environment. */
 #define MI355_FLAG_FUSED 1
+/* Experiment, off by default: mi355_diff_pairs_batch as ONE pass with a chained scan (decoupled look-back)
+ * instead of the three-kernel log path; bit-exact, on the MI355X as fast on dense pairs and slower on sparse
+ * ones (csrc/diff_chain.hip says why).  Also MI355_CHAIN=1 in the environment. */
+#define MI355_FLAG_CHAIN 2
 
 /* ---- life cycle: CUDACore::CUDACore (kernels.cu:377-428) without the uploads ------------------ */
 int mi355_create(const mi355_config *cfg, mi355_core **out);
