@@ -30,6 +30,62 @@ from cudavideostream_amd import CUDACore, synth  # noqa: E402
 from cudavideostream_amd import gather as gx  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+KERNELS = ("k_diff_pack", "k_scan_groups", "k_expand")   # the path's three kernels, in launch order
+
+
+def lib_sha256():
+    import hashlib
+    from cudavideostream_amd import lib as _lib
+    try:
+        return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+    except Exception:
+        return None
+
+
+def pmc_counters(B, W, H):
+    """Counter bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_summary.json), or None
+    when they were taken at another configuration or on another build of the library (stale numbers are not
+    reported)."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return None
+    if (rec.get("batch"), rec.get("width"), rec.get("height")) != (B, W, H):
+        return None
+    if not rec.get("lib_sha256") or rec["lib_sha256"] != lib_sha256():
+        return None
+    return rec
+
+
+def path_roofline(alg_bytes, ms, launches, pair, pmc=None):
+    """roofline object of one configuration of the path.  achieved = ALGORITHMIC bytes (2N + 5P per
+    frame) over the time of ALL kernels of the path (pack + scan + expand, HIP events on the core's stream)."""
+    per = [m / max(launches, 1) for m in ms]
+    total_ms = sum(per)
+    achieved = alg_bytes / (total_ms * 1e-3) / 1e9
+    names = ("mi355::k_diff_pack<%s,true>" % ("true" if pair else "false"), "mi355::k_scan_groups",
+             "mi355::k_expand<false>")
+    kernels = []
+    for short, name, m in zip(KERNELS, names, per):
+        k = {"kernel": name, "avg_us": round(m * 1e3, 2)}
+        c = pmc["kernels"].get(short) if pmc else None
+        if c:
+            moved = c["read_bytes"] + c["write_bytes"]
+            k.update({"bytes_moved": moved, "read_bytes": c["read_bytes"], "write_bytes": c["write_bytes"],
+                      "frac_of_peak": round(moved / (m * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
+        kernels.append(k)
+    frac = achieved / HBM_PEAK_GBPS
+    assert 0.0 < frac <= 1.0, f"roofline fraction {frac} outside (0, 1]"
+    out = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": round(frac, 4),
+           "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
+           "kernel": "+".join(KERNELS), "kernel_ms": round(total_ms, 4),
+           "algorithmic_bytes_per_launch": int(alg_bytes), "kernels": kernels}
+    if pmc:
+        out["traffic_source"] = f"profiles/pmc_summary.json ({pmc.get('tag')}, separate --pmc FETCH_SIZE / WRITE_SIZE passes, same library build)"
+        out["actual_gbps"] = round(pmc["hbm_bytes_per_launch"] / (total_ms * 1e-3) / 1e9, 1)
+    return out
 
 
 def metric_name(W, H):
@@ -59,6 +115,7 @@ def parse():
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-pair", action="store_true")
     p.add_argument("--no-host-path", action="store_true")
+    p.add_argument("--no-filters", action="store_true", help="skip the config3 / config4 objects")
     return p.parse_args()
 
 
@@ -233,25 +290,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    ms_pack, ms_total, launches = core.get_timing()
+    ms_pack, ms_scan, ms_expand, launches = core.get_kernel_timing()
     core.set_timing(False)
     off = d_off.cpu().numpy().view(np.uint32)
     p_total = int(off[-1])
     assert p_total <= cap, "output capacity too small for this stream"
 
     if rank == 0:
-        pack_ms = ms_pack / max(launches, 1)
         alg_bytes = 2.0 * n * B + 5.0 * p_total          # B_alg = 2N + 5P per frame
-        achieved = alg_bytes / (pack_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("batch") == B and rec.get("width") == W and rec.get("height") == H:
-                    traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        pmc = None if rr else pmc_counters(B, W, H)
         out = {
             "metric": metric_name(W, H),
             "value": round(world * B * K / elapsed, 1),
@@ -274,22 +321,13 @@ def main():
                        "parallelism": (f"frames round-robin over {world} ranks" if rr else
                                        f"{world} independent streams" if world > 1 else "1 stream"),
                        "gather": args.gather if world > 1 else "n/a"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": traffic,
-                         "kernel": "mi355::k_diff_pack<true,true>" if rr else "mi355::k_diff_pack<false,true>",
-                         "kernel_ms": round(pack_ms, 4),
-                         "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "read_gbps_2N": round(2.0 * n * B / (pack_ms * 1e-3) / 1e9, 1),
-                         # what the kernel really moves (PMC traffic / its duration): the state never leaves
-                         # the registers, so this is below the algorithmic figure
-                         "actual_gbps": round(traffic / (pack_ms * 1e-3) / 1e9, 1) if traffic else None,
-                         "all_kernels_ms": round(ms_total / max(launches, 1), 4)},
+            "roofline": path_roofline(alg_bytes, (ms_pack, ms_scan, ms_expand), launches, rr, pmc),
         }
-        if rr:
-            out["roofline"]["traffic"] = None   # the PMC summary is for the stream kernel
         if world == 1 and not args.no_pair and not rr:
             out["pair_mode"] = pair_mode(args, core, frames, d_off, d_xs, d_df, cap, n)
+            out["regimes"] = regimes(args, dev)
+        if world == 1 and not args.no_filters and not rr:
+            out.update(filter_configs(args, dev))
         if world == 1 and not args.no_host_path:
             out["host_path"] = host_path(args, base, frames)
         if world == 1 and not args.no_cpu and not rr:
@@ -370,6 +408,33 @@ def host_path(args, base, frames, reps=60):
             "pcie_h2d_gbps": round(preps * n / dt_pipe / 1e9, 2)}
 
 
+def timed_path(core, fn, reps, warm=3):
+    """Runs fn() reps times with the core's kernel timers on: (seconds per call, (pack, scan, expand) ms sums, launches)."""
+    core.set_timing(True)
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    core.reset_timing()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    a, b, c, launches = core.get_kernel_timing()
+    core.set_timing(False)
+    return dt / reps, (a, b, c), launches
+
+
+def path_line(B, n, p, sec_per_call, ms, launches, pair):
+    """Secondary line of one regime: whole-path rate and roofline fraction, ALL kernels in the denominator."""
+    alg = 2.0 * n * B + 5.0 * p
+    r = path_roofline(alg, ms, launches, pair)
+    return {"frames_per_s": round(B / sec_per_call, 1), "frames_per_launch": B,
+            "changed_bytes_per_frame": round(p / B, 1), "all_kernels_ms": r["kernel_ms"],
+            "achieved_gbps": r["achieved"], "frac": r["frac"],
+            "kernels_us": [k["avg_us"] for k in r["kernels"]]}
+
+
 def pair_mode(args, core, frames, d_off, d_xs, d_df, cap, n):
     """Secondary line: stateless frame pairs with NO reuse between the two operands (cur = first half
     of the resident frames, prev = second half), i.e. 2N bytes of HBM reads per frame -- the plain
@@ -377,27 +442,96 @@ def pair_mode(args, core, frames, d_off, d_xs, d_df, cap, n):
     than in the stream.)"""
     B = frames.shape[0] // 2
     cur, prev = frames[:B], frames[B:2 * B]
-    core.set_timing(True)
-    core.reset_timing()
-    for _ in range(3):
-        core.diff_pairs_batch(cur, prev, B, d_off, d_xs, d_df, cap)
-    torch.cuda.synchronize()
-    core.reset_timing()
-    reps = 20
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        core.diff_pairs_batch(cur, prev, B, d_off, d_xs, d_df, cap)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ms_pack, _, launches = core.get_timing()
-    core.set_timing(False)
+    sec, ms, launches = timed_path(core, lambda: core.diff_pairs_batch(cur, prev, B, d_off, d_xs, d_df, cap), 20)
     p = int(d_off.cpu().numpy().view(np.uint32)[B])
-    pack_ms = ms_pack / max(launches, 1)
-    alg = 2.0 * n * B + 5.0 * p
-    return {"frames_per_s": round(B * reps / dt, 1), "frames_per_launch": B, "kernel_ms": round(pack_ms, 4),
-            "achieved_gbps": round(alg / (pack_ms * 1e-3) / 1e9, 1),
-            "frac": round(alg / (pack_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-            "changed_bytes_per_frame": round(p / B, 1)}
+    return path_line(B, n, p, sec, ms, launches, True)
+
+
+def regimes(args, dev, B=32):
+    """Secondary lines: the same path on the other input regimes of SURVEY.md 8d, 32-frame batches, whole-path
+    fractions: S0 refrand pairs (the generator of tests/algorithms_benchmarks.cu:4-10, P ~ 0.85 N), every byte
+    changed (P = N), nothing changed (P = 0)."""
+    W, H = args.width, args.height
+    n = 3 * W * H
+    cap = B * n
+    d_off = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    d_xs = torch.empty(cap, dtype=torch.int32, device=dev)
+    d_df = torch.empty(cap, dtype=torch.uint8, device=dev)
+    rnd = torch.stack([synth.refrand_frame(n, 100 + t, device=dev) for t in range(2 * B)])
+    flip = rnd[:B] ^ 0x80
+    out = {}
+    with CUDACore(W, H, max_batch=B) as core:
+        core.use_torch_stream()
+        for name, cur, prev in (("S0_refrand_pairs", rnd[B:], rnd[:B]), ("P_eq_N_pairs", flip, rnd[:B]),
+                                ("P_eq_0_pairs", rnd[:B], rnd[:B].clone())):
+            sec, ms, launches = timed_path(core, lambda: core.diff_pairs_batch(cur, prev, B, d_off, d_xs, d_df, cap), 10, 2)
+            p = int(d_off.cpu().numpy().view(np.uint32)[B])
+            out[name] = path_line(B, n, p, sec, ms, launches, True)
+    return out
+
+
+def filter_configs(args, dev, B=96, reps=10):
+    """BASELINE configs 3 and 4 end to end on a resident batch (what the server does with a frame when the
+    visualiser / noise filter is on, kernels.cu:457-520): the visualiser's frame AND the packed diff stream.
+      config3: weighted grayscale + histogram + two-max + binarize (fused: the gray frame is never stored), then
+               diff+threshold+pack.  Algorithmic bytes per frame: N (colour) + N (binarized out) for the visualiser
+               (the histogram needs a second look at the colour frame only because the threshold is global)
+               + 2N + 5P for the diff.
+      config4: 3x3 noise filter (N + N), diff+threshold+pack of the filtered frames (2N + 5P), red motion map
+               from the packed indices (N cleared + P/3 painted ~ N).
+    frac = algorithmic bytes / all kernels of the chain (HIP events on the stream) / 8 TB/s."""
+    from cudavideostream_amd import lib as L
+    W, H = args.width, args.height
+    n = 3 * W * H
+    _, frames = synth.webcam_stream(B + 1, W, H, seed=33, device=dev)
+    cur = frames[1:]
+    vis = torch.empty((B, n), dtype=torch.uint8, device=dev)
+    filt = torch.empty((B, n), dtype=torch.uint8, device=dev)
+    cap = B * n // 4
+    d_off = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    d_xs = torch.empty(cap, dtype=torch.int32, device=dev)
+    d_df = torch.empty(cap, dtype=torch.uint8, device=dev)
+    g = np.exp(-(np.arange(-1, 2)[:, None] ** 2 + np.arange(-1, 2)[None, :] ** 2) / (2.0 * 1.5 * 1.5))
+    k = (g / g.sum()).astype(np.float32).reshape(-1)
+    res = {}
+    with CUDACore(W, H, k=k, max_batch=B) as core:
+        core.use_torch_stream()
+        core.set_state(frames[0].cpu().numpy())
+
+        def config3():
+            core.filter_batch(L.OP_GRAY_WEIGHTED_BINARIZE, cur, vis, B)
+            core.diff_stream_batch(cur, B, d_off, d_xs, d_df, cap)
+
+        def config4():
+            core.filter_batch(L.OP_CONV3X3, cur, filt, B)
+            core.diff_stream_batch(filt, B, d_off, d_xs, d_df, cap)
+            core.red_stream_batch(d_off, d_xs, B, vis)
+
+        for name, fn, fixed in (("config3", config3, 4.0 * n), ("config4", config4, 5.0 * n)):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(reps):
+                fn()
+            ev1.record()
+            torch.cuda.synchronize()
+            us = ev0.elapsed_time(ev1) * 1e3 / (reps * B)
+            p = (int(d_off[B].item()) & 0xFFFFFFFF) / B
+            alg = fixed + 5.0 * p
+            gbps = alg / (us * 1e-6) / 1e9
+            res[name] = {"workload": BASELINE_CONFIGS.get(name, name), "us_per_frame": round(us, 3),
+                         "frames_per_s": round(1e6 / us, 1), "frames_per_launch": B,
+                         "changed_bytes_per_frame": round(p, 1), "algorithmic_bytes_per_frame": int(alg),
+                         "achieved_gbps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4)}
+    return res
+
+
+BASELINE_CONFIGS = {
+    "config3": "BASELINE configs[2]: 1080p diff + grayscale-weighted + binarize filter chain, 1xMI355X",
+    "config4": "BASELINE configs[3]: 1080p diff + motion heat-map (red) + noise filter, 1xMI355X",
+}
 
 
 if __name__ == "__main__":

@@ -267,6 +267,12 @@ class CUDACore:
     def reset_timing(self):
         _l.check(self._lib.mi355_reset_timing(self._h))
 
+    def get_kernel_timing(self):
+        """(ms in k_diff_pack, ms in k_scan_groups, ms in k_expand, launches) since reset."""
+        a, b, d, n = C.c_double(0), C.c_double(0), C.c_double(0), C.c_int(0)
+        _l.check(self._lib.mi355_get_kernel_timing(self._h, C.byref(a), C.byref(b), C.byref(d), C.byref(n)))
+        return a.value, b.value, d.value, n.value
+
     def get_timing(self):
         """(ms in the diff/threshold/pack kernel, ms in pack+scan+gather, launches) since reset."""
         a, b, n = C.c_double(0), C.c_double(0), C.c_int(0)

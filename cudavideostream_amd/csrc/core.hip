@@ -99,13 +99,13 @@ struct mi355_core {
     int64_t next_ticket = 0;
     hipStream_t up_stream = nullptr, down_stream = nullptr;
 
-    // timing: ring of event triplets {before pack, after pack, after gather}, harvested lazily so
+    // timing: ring of event sets {before pack, after pack, after scan, after expand}, harvested lazily so
     // that timed batches still queue back to back
-    static constexpr int kEvRing = 32;
+    static constexpr int kEvRing = 32, kEvPer = 4;
     bool timing = false;
-    hipEvent_t ev[kEvRing][3] = {};
+    hipEvent_t ev[kEvRing][kEvPer] = {};
     int ev_head = 0, ev_count = 0;  // oldest pending slot, number pending
-    double ms_pack = 0, ms_total = 0;
+    double ms_pack = 0, ms_scan = 0, ms_expand = 0, ms_total = 0;
     int launches = 0;
 };
 
@@ -128,12 +128,16 @@ int use_device(const mi355_core *c) {
 int harvest_timing(mi355_core *c, int keep = 0) {
     while (c->ev_count > keep) {
         hipEvent_t *e = c->ev[c->ev_head];
-        HIP_TRY(hipEventSynchronize(e[2]));
-        float a = 0, b = 0;
+        HIP_TRY(hipEventSynchronize(e[3]));
+        float a = 0, b = 0, d = 0, t = 0;
         HIP_TRY(hipEventElapsedTime(&a, e[0], e[1]));
-        HIP_TRY(hipEventElapsedTime(&b, e[0], e[2]));
+        HIP_TRY(hipEventElapsedTime(&b, e[1], e[2]));
+        HIP_TRY(hipEventElapsedTime(&d, e[2], e[3]));
+        HIP_TRY(hipEventElapsedTime(&t, e[0], e[3]));
         c->ms_pack += a;
-        c->ms_total += b;
+        c->ms_scan += b;
+        c->ms_expand += d;
+        c->ms_total += t;
         c->launches += 1;
         c->ev_head = (c->ev_head + 1) % mi355_core::kEvRing;
         c->ev_count -= 1;
@@ -304,8 +308,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     if (c->fused && !pair && !d_wire && (((uintptr_t)d_cur | stride) & 15u) == 0) {
         if (int rc = run_fused(c, d_cur, stride, nframes, d_offsets, d_xs, d_diff, capacity)) return rc;
         if (tev) {
-            HIP_TRY(hipEventRecord(tev[1], c->stream));
-            HIP_TRY(hipEventRecord(tev[2], c->stream));
+            for (int i = 1; i < mi355_core::kEvPer; i++) HIP_TRY(hipEventRecord(tev[i], c->stream));
             c->ev_count += 1;
         }
         return MI355_OK;
@@ -313,8 +316,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     if (c->chain && pair && !d_wire && (((uintptr_t)d_cur | (uintptr_t)d_prev | stride) & 15u) == 0) {
         if (int rc = run_chain(c, d_cur, d_prev, stride, nframes, d_offsets, d_xs, d_diff, capacity)) return rc;
         if (tev) {
-            HIP_TRY(hipEventRecord(tev[1], c->stream));
-            HIP_TRY(hipEventRecord(tev[2], c->stream));
+            for (int i = 1; i < mi355_core::kEvPer; i++) HIP_TRY(hipEventRecord(tev[i], c->stream));
             c->ev_count += 1;
         }
         return MI355_OK;
@@ -335,6 +337,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     if (tev) HIP_TRY(hipEventRecord(tev[1], c->stream));
     HIP_TRY(launch_scan(c->meta, c->groff, c->totals, c->ntiles, nframes, (uint32_t *)d_offsets,
                         c->totals + c->cfg.max_batch, c->stream));
+    if (tev) HIP_TRY(hipEventRecord(tev[2], c->stream));
     ExpandArgs g{};
     g.rec = c->rec;
     g.meta = c->meta;
@@ -347,7 +350,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     g.capacity = capacity;
     HIP_TRY(launch_expand(g, nframes, c->stream));
     if (tev) {
-        HIP_TRY(hipEventRecord(tev[2], c->stream));
+        HIP_TRY(hipEventRecord(tev[3], c->stream));
         c->ev_count += 1;
     }
     return MI355_OK;
@@ -390,7 +393,7 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     int rc = use_device(c);
     if (!rc) { e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipStreamCreate", e); }
     c->stream = c->own_stream;
-    for (int i = 0; i < mi355_core::kEvRing * 3 && !rc; i++) { e = hipEventCreate(&c->ev[i / 3][i % 3]); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipEventCreate", e); }
+    for (int i = 0; i < mi355_core::kEvRing * mi355_core::kEvPer && !rc; i++) { e = hipEventCreate(&c->ev[i / mi355_core::kEvPer][i % mi355_core::kEvPer]); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipEventCreate", e); }
     if (!rc) rc = dev_alloc(c, &c->state, N + 16);
     if (!rc) rc = dev_alloc(c, &c->in, N + 16);
     if (!rc) rc = dev_alloc(c, &c->aux, N + 16);
@@ -1020,11 +1023,22 @@ int mi355_get_timing(mi355_core *c, double *ms_pack, double *ms_total, int *laun
     return MI355_OK;
 }
 
+int mi355_get_kernel_timing(mi355_core *c, double *ms_pack, double *ms_scan, double *ms_expand, int *launches) {
+    if (!c) return fail(MI355_ERR_INVALID, "null core");
+    if (int rc = use_device(c)) return rc;
+    if (int rc = harvest_timing(c)) return rc;
+    if (ms_pack) *ms_pack = c->ms_pack;
+    if (ms_scan) *ms_scan = c->ms_scan;
+    if (ms_expand) *ms_expand = c->ms_expand;
+    if (launches) *launches = c->launches;
+    return MI355_OK;
+}
+
 int mi355_reset_timing(mi355_core *c) {
     if (!c) return fail(MI355_ERR_INVALID, "null core");
     if (int rc = use_device(c)) return rc;
     if (int rc = harvest_timing(c)) return rc;
-    c->ms_pack = c->ms_total = 0;
+    c->ms_pack = c->ms_scan = c->ms_expand = c->ms_total = 0;
     c->launches = 0;
     return MI355_OK;
 }

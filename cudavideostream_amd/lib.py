@@ -92,6 +92,8 @@ SYMBOLS = {
     "mi355_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "mi355_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int)]),
+    "mi355_get_kernel_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "mi355_reset_timing": (C.c_int, [C.c_void_p]),
 }
 

@@ -243,6 +243,8 @@ int mi355_download(mi355_core *core, void *host_dst, const void *d_src, size_t b
  * ms_pack = the diff/threshold/pack kernel alone, ms_total = pack + scan + gather. */
 int mi355_set_timing(mi355_core *core, int enabled);
 int mi355_get_timing(mi355_core *core, double *ms_pack, double *ms_total, int *launches);
+/* The same sums per kernel: pack (k_diff_pack), scan (k_scan_groups), expand (k_expand); their sum is ms_total. */
+int mi355_get_kernel_timing(mi355_core *core, double *ms_pack, double *ms_scan, double *ms_expand, int *launches);
 int mi355_reset_timing(mi355_core *core);
 
 #ifdef __cplusplus
