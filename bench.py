@@ -255,6 +255,38 @@ def main():
     core.use_torch_stream()
     core.set_state(base.cpu().numpy())
 
+    # The exchange step below the C-ABI (mi355_group_gather: RCCL all-gather of counts + point-to-point sends to
+    # rank 0, csrc/group.hip): this process's core joins a group of `world` ranks with an id rank 0 makes and
+    # torch.distributed hands around.  If the group cannot be formed (a harness matter, not the path's), the
+    # torch.distributed form of the same exchange (cudavideostream_amd/gather.py) is used and named in the line.
+    group, gather_impl = None, "n/a"
+    if world > 1 and args.gather != "none":
+        gather_impl = "mi355_group_gather (RCCL, csrc/group.hip)"
+        try:
+            from cudavideostream_amd.group import CUDAGroup, unique_id
+            ident = torch.from_numpy(unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(dev)
+            dist.broadcast(ident, src=0)
+            group = CUDAGroup.adopt(core, world, rank, ident.cpu().numpy())
+            root_cap = world * cap if rank == 0 else 0
+            r_off = torch.zeros((world, B + 1), dtype=torch.int32, device=dev) if rank == 0 else None
+            r_xs = torch.empty(root_cap, dtype=torch.int32, device=dev) if rank == 0 else None
+            r_df = torch.empty(root_cap, dtype=torch.uint8, device=dev) if rank == 0 else None
+        except Exception as e:   # noqa: BLE001
+            group = None
+            gather_impl = f"torch.distributed (mi355_group unavailable: {repr(e)[:100]})"
+        ok = torch.tensor([1 if group is not None else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank takes the same way
+        if int(ok.item()) == 0 and group is not None:
+            group.close()
+            group = None
+            gather_impl = "torch.distributed (mi355_group unavailable on another rank)"
+
+    def exchange_payload():
+        if group is not None:
+            group.gather(0, B, [d_off], [d_xs], [d_df], r_off, r_xs, r_df, world * cap if rank == 0 else 0)
+        else:
+            gx.gather_payload(d_off, d_xs, d_df, dst=0)
+
     def step(last):
         if rr:
             core.diff_pairs_batch(frames, prevs, B, d_off, d_xs, d_df, cap)
@@ -265,7 +297,7 @@ def main():
             # of the changed-pixel stream to rank 0: of the final batch ("last", the default), of every
             # batch ("every"), or the per-frame index every step and the payload at the end ("index")
             if args.gather == "every" or (args.gather in ("last", "index") and last):
-                gx.gather_payload(d_off, d_xs, d_df, dst=0)
+                exchange_payload()
             elif args.gather == "index":
                 gx.gather_index(d_off, dst=0)
 
@@ -320,7 +352,7 @@ def main():
                        "frames_per_step": B, "changed_bytes_per_frame": round(p_total / B, 1),
                        "parallelism": (f"frames round-robin over {world} ranks" if rr else
                                        f"{world} independent streams" if world > 1 else "1 stream"),
-                       "gather": args.gather if world > 1 else "n/a"},
+                       "gather": args.gather if world > 1 else "n/a", "gather_impl": gather_impl},
             "roofline": path_roofline(alg_bytes, (ms_pack, ms_scan, ms_expand), launches, rr, pmc),
         }
         if world == 1 and not args.no_pair and not rr:
@@ -338,6 +370,8 @@ def main():
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
+    if group is not None:
+        group.close()
     core.close()
     if dist:
         dist.barrier()

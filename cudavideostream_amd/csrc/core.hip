@@ -109,6 +109,12 @@ struct mi355_core {
     int launches = 0;
 };
 
+namespace mi355 {
+int set_error(int code, const char *what) { return fail(code, what); }
+hipStream_t core_stream(const ::mi355_core *c) { return c->stream; }
+int core_device(const ::mi355_core *c) { return c->device; }
+}  // namespace mi355
+
 namespace {
 
 template <class T>

@@ -1,0 +1,326 @@
+// group.hip -- several GPUs of one node behind the C-ABI (include/mi355diff.h, "multi-GPU"): one core per device,
+// RCCL over xGMI only for the final changed-pixel gather.
+//
+// The reference has no multi-GPU code (server/src/kernels.cu:385 uses device 0); this is BASELINE.json's
+// north star for the path: "independent frames shard trivially across the 8 GPUs of one node with RCCL over
+// xGMI only for the final changed-pixel gather".  The data path has no collective: every member runs its own
+// stream, its own dealt-out frame pairs (E1 round robin, BASELINE config 5) or its row band
+// (E2) through the ordinary single-device entry points, concurrently, each on its own device and stream.
+//
+// The gather is a gather-v of (per-frame index, xs, diff) to one root:
+//   1. ncclAllGather of one count per rank (everybody learns every total; one host synchronisation, as the
+//      reference reads h_pos back before its copies, kernels.cu:507-508);
+//   2. inside one ncclGroupStart/End: every other rank ncclSend's its index, xs and diff to the root, the root
+//      posts the matching ncclRecv's at rank-ordered places -- up to 7 concurrent point-to-point transfers into
+//      the root over its 7 direct xGMI links, no ring;
+//   3. the root's own part is a device-to-device copy.
+//
+// A group lives either in one process over several devices (mi355_group_create: ncclCommInitAll; a C++ server
+// linked against libmi355compat.a) or as one member per process (mi355_group_adopt_rank: ncclCommInitRank with an
+// id made by mi355_group_unique_id and handed around by the launcher; bench.py under torch.distributed.run).
+//
+// RCCL is bound at the first group call with dlopen("librccl.so.1"): a copy the process has already loaded
+// (PyTorch ships one) is reused, so that there is one RCCL per process; single-GPU users never load it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/mi355diff.h"
+#include "internal.h"
+
+using namespace mi355;
+
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+Rccl g_rccl;
+
+int bind_rccl() {
+    if (g_rccl.handle) return MI355_OK;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);   // the copy the process already has, if any
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return set_error(MI355_ERR_STATE, "librccl.so.1 not found: the multi-GPU entry points need RCCL");
+    Rccl r;
+    r.handle = h;
+#define BIND(name)                                                                                     \
+    r.name = (decltype(r.name))dlsym(h, "nccl" #name);                                                 \
+    if (!r.name) return set_error(MI355_ERR_STATE, "librccl.so.1 lacks nccl" #name);
+    BIND(GetUniqueId) BIND(CommInitRank) BIND(CommInitAll) BIND(CommDestroy) BIND(AllGather) BIND(Send) BIND(Recv)
+    BIND(GroupStart) BIND(GroupEnd) BIND(GetErrorString)
+#undef BIND
+    g_rccl = r;
+    return MI355_OK;
+}
+
+int rccl_fail(const char *what, ncclResult_t e) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "RCCL error");
+    return set_error(MI355_ERR_HIP, buf);
+}
+
+#define RCCL_TRY(expr)                                           \
+    do {                                                         \
+        ncclResult_t _e = (expr);                                \
+        if (_e != ncclSuccess) return rccl_fail(#expr, _e);      \
+    } while (0)
+#define HIP_TRY_G(expr)                                                    \
+    do {                                                                   \
+        hipError_t _e = (expr);                                            \
+        if (_e != hipSuccess) {                                            \
+            char _b[256];                                                  \
+            snprintf(_b, sizeof _b, "%s: %s", #expr, hipGetErrorString(_e)); \
+            return set_error(MI355_ERR_HIP, _b);                           \
+        }                                                                  \
+    } while (0)
+
+struct Member {
+    mi355_core *core = nullptr;
+    bool owned = false;
+    int rank = 0;              // rank in the group
+    ncclComm_t comm = nullptr;
+    uint32_t *d_counts = nullptr;   // [nranks] on the member's device: every rank's total of the batch being gathered
+};
+
+}  // namespace
+
+struct mi355_group {
+    int nranks = 0;
+    std::vector<Member> local;
+    std::vector<uint32_t> h_counts;
+};
+
+namespace {
+
+Member *member_of_rank(mi355_group *g, int rank) {
+    for (Member &m : g->local)
+        if (m.rank == rank) return &m;
+    return nullptr;
+}
+
+int check_group(const mi355_group *g) {
+    if (!g) return set_error(MI355_ERR_INVALID, "null group");
+    return MI355_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355_group_unique_id(void *id128) {
+    if (!id128) return set_error(MI355_ERR_INVALID, "null argument");
+    if (int rc = bind_rccl()) return rc;
+    static_assert(sizeof(ncclUniqueId) == MI355_GROUP_ID_BYTES, "id size");
+    ncclUniqueId id;
+    RCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof id);
+    return MI355_OK;
+}
+
+void mi355_group_destroy(mi355_group *g) {
+    if (!g) return;
+    for (Member &m : g->local) {
+        if (m.core) {
+            (void)hipSetDevice(core_device(m.core));
+            (void)hipStreamSynchronize(core_stream(m.core));
+        }
+        if (m.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m.comm);
+        if (m.d_counts) (void)hipFree(m.d_counts);
+        if (m.owned) mi355_destroy(m.core);
+    }
+    delete g;
+}
+
+int mi355_group_create(const mi355_config *cfg, int ndev, const int *devices, mi355_group **out) {
+    if (!cfg || !out) return set_error(MI355_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (ndev < 1 || ndev > 64) return set_error(MI355_ERR_INVALID, "ndev outside [1, 64]");
+    if (int rc = bind_rccl()) return rc;
+    mi355_group *g = new (std::nothrow) mi355_group;
+    if (!g) return set_error(MI355_ERR_INVALID, "out of host memory");
+    g->nranks = ndev;
+    g->local.resize(ndev);
+    g->h_counts.resize(ndev);
+    std::vector<int> devs(ndev);
+    int rc = MI355_OK;
+    for (int i = 0; i < ndev && !rc; i++) {
+        devs[i] = devices ? devices[i] : i;
+        mi355_config c = *cfg;
+        c.device = devs[i];
+        Member &m = g->local[i];
+        m.rank = i;
+        m.owned = true;
+        rc = mi355_create(&c, &m.core);
+        if (!rc && hipSetDevice(devs[i]) != hipSuccess) rc = set_error(MI355_ERR_HIP, "hipSetDevice");
+        if (!rc && hipMalloc((void **)&m.d_counts, sizeof(uint32_t) * ndev) != hipSuccess) rc = set_error(MI355_ERR_HIP, "hipMalloc");
+    }
+    if (!rc) {
+        std::vector<ncclComm_t> comms(ndev);
+        const ncclResult_t e = g_rccl.CommInitAll(comms.data(), ndev, devs.data());
+        if (e != ncclSuccess) rc = rccl_fail("ncclCommInitAll", e);
+        else for (int i = 0; i < ndev; i++) g->local[i].comm = comms[i];
+    }
+    if (rc) { mi355_group_destroy(g); return rc; }
+    *out = g;
+    return MI355_OK;
+}
+
+int mi355_group_adopt_rank(mi355_core *core, int nranks, int rank, const void *id128, mi355_group **out) {
+    if (!core || !id128 || !out) return set_error(MI355_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return set_error(MI355_ERR_INVALID, "rank outside [0, nranks)");
+    if (int rc = bind_rccl()) return rc;
+    mi355_group *g = new (std::nothrow) mi355_group;
+    if (!g) return set_error(MI355_ERR_INVALID, "out of host memory");
+    g->nranks = nranks;
+    g->local.resize(1);
+    g->h_counts.resize(nranks);
+    Member &m = g->local[0];
+    m.core = core;
+    m.rank = rank;
+    int rc = MI355_OK;
+    if (hipSetDevice(core_device(core)) != hipSuccess) rc = set_error(MI355_ERR_HIP, "hipSetDevice");
+    if (!rc && hipMalloc((void **)&m.d_counts, sizeof(uint32_t) * nranks) != hipSuccess) rc = set_error(MI355_ERR_HIP, "hipMalloc");
+    if (!rc) {
+        ncclUniqueId id;
+        memcpy(&id, id128, sizeof id);
+        const ncclResult_t e = g_rccl.CommInitRank(&m.comm, nranks, id, rank);
+        if (e != ncclSuccess) rc = rccl_fail("ncclCommInitRank", e);
+    }
+    if (rc) { mi355_group_destroy(g); return rc; }
+    *out = g;
+    return MI355_OK;
+}
+
+int mi355_group_ranks(const mi355_group *g) { return g ? g->nranks : 0; }
+int mi355_group_local_members(const mi355_group *g) { return g ? (int)g->local.size() : 0; }
+mi355_core *mi355_group_core(mi355_group *g, int i) {
+    return g && i >= 0 && i < (int)g->local.size() ? g->local[i].core : nullptr;
+}
+int mi355_group_rank_of(const mi355_group *g, int i) {
+    return g && i >= 0 && i < (int)g->local.size() ? g->local[i].rank : -1;
+}
+
+int mi355_group_diff_stream_batch(mi355_group *g, const void *const *d_frames, size_t stride_bytes, int nframes,
+                                  void *const *d_offsets, void *const *d_xs, void *const *d_diff, size_t capacity) {
+    if (int rc = check_group(g)) return rc;
+    if (!d_frames || !d_offsets || !d_xs || !d_diff) return set_error(MI355_ERR_INVALID, "null argument");
+    for (size_t i = 0; i < g->local.size(); i++)   // asynchronous on every member's stream: the devices run side by side
+        if (int rc = mi355_diff_stream_batch(g->local[i].core, d_frames[i], stride_bytes, nframes, d_offsets[i], d_xs[i],
+                                             d_diff[i], capacity))
+            return rc;
+    return MI355_OK;
+}
+
+int mi355_group_diff_pairs_batch(mi355_group *g, const void *const *d_cur, const void *const *d_prev,
+                                 size_t stride_bytes, int nframes, void *const *d_offsets, void *const *d_xs,
+                                 void *const *d_diff, size_t capacity) {
+    if (int rc = check_group(g)) return rc;
+    if (!d_cur || !d_prev || !d_offsets || !d_xs || !d_diff) return set_error(MI355_ERR_INVALID, "null argument");
+    for (size_t i = 0; i < g->local.size(); i++)
+        if (int rc = mi355_diff_pairs_batch(g->local[i].core, d_cur[i], d_prev[i], stride_bytes, nframes, d_offsets[i],
+                                            d_xs[i], d_diff[i], capacity))
+            return rc;
+    return MI355_OK;
+}
+
+int mi355_group_synchronize(mi355_group *g) {
+    if (int rc = check_group(g)) return rc;
+    for (Member &m : g->local)
+        if (int rc = mi355_synchronize(m.core)) return rc;
+    return MI355_OK;
+}
+
+int mi355_group_gather(mi355_group *g, int root, int nframes, const void *const *d_offsets, const void *const *d_xs,
+                       const void *const *d_diff, void *d_root_offsets, void *d_root_xs, void *d_root_diff,
+                       size_t root_capacity, uint64_t *h_counts) {
+    if (int rc = check_group(g)) return rc;
+    if (root < 0 || root >= g->nranks) return set_error(MI355_ERR_INVALID, "root outside [0, ranks)");
+    if (nframes < 0) return set_error(MI355_ERR_INVALID, "nframes < 0");
+    if (!d_offsets || !d_xs || !d_diff) return set_error(MI355_ERR_INVALID, "null argument");
+    Member *rootm = member_of_rank(g, root);
+    if (rootm && (!d_root_offsets || (root_capacity && (!d_root_xs || !d_root_diff))))
+        return set_error(MI355_ERR_INVALID, "the root is a member of this process: its buffers are needed");
+    const int R = g->nranks;
+    // 1. every rank's total: offsets[nframes] of its batch
+    RCCL_TRY(g_rccl.GroupStart());
+    for (size_t i = 0; i < g->local.size(); i++) {
+        Member &m = g->local[i];
+        HIP_TRY_G(hipSetDevice(core_device(m.core)));
+        RCCL_TRY(g_rccl.AllGather((const uint32_t *)d_offsets[i] + nframes, m.d_counts, 1, ncclUint32, m.comm,
+                                  core_stream(m.core)));
+    }
+    RCCL_TRY(g_rccl.GroupEnd());
+    {
+        Member &m = g->local[0];
+        HIP_TRY_G(hipSetDevice(core_device(m.core)));
+        HIP_TRY_G(hipMemcpyAsync(g->h_counts.data(), m.d_counts, sizeof(uint32_t) * R, hipMemcpyDeviceToHost, core_stream(m.core)));
+        HIP_TRY_G(hipStreamSynchronize(core_stream(m.core)));
+    }
+    std::vector<size_t> base(R + 1, 0);
+    for (int r = 0; r < R; r++) {
+        base[r + 1] = base[r] + g->h_counts[r];
+        if (h_counts) h_counts[r] = g->h_counts[r];
+    }
+    if (rootm && base[R] > root_capacity) return set_error(MI355_ERR_INVALID, "root capacity below the gathered total");
+    // 2. index and payload travel point to point, all transfers of the step in one RCCL group
+    const size_t row = (size_t)nframes + 1;
+    RCCL_TRY(g_rccl.GroupStart());
+    for (size_t i = 0; i < g->local.size(); i++) {
+        Member &m = g->local[i];
+        HIP_TRY_G(hipSetDevice(core_device(m.core)));
+        hipStream_t s = core_stream(m.core);
+        if (m.rank == root) {
+            for (int r = 0; r < R; r++) {
+                if (r == root) continue;
+                const size_t c = g->h_counts[r];
+                RCCL_TRY(g_rccl.Recv((uint32_t *)d_root_offsets + (size_t)r * row, row, ncclUint32, r, m.comm, s));
+                if (c) {
+                    RCCL_TRY(g_rccl.Recv((int32_t *)d_root_xs + base[r], c, ncclInt32, r, m.comm, s));
+                    RCCL_TRY(g_rccl.Recv((uint8_t *)d_root_diff + base[r], c, ncclUint8, r, m.comm, s));
+                }
+            }
+        } else {
+            const size_t c = g->h_counts[m.rank];
+            RCCL_TRY(g_rccl.Send(d_offsets[i], row, ncclUint32, root, m.comm, s));
+            if (c) {
+                RCCL_TRY(g_rccl.Send(d_xs[i], c, ncclInt32, root, m.comm, s));
+                RCCL_TRY(g_rccl.Send(d_diff[i], c, ncclUint8, root, m.comm, s));
+            }
+        }
+    }
+    RCCL_TRY(g_rccl.GroupEnd());
+    // 3. the root's own part
+    if (rootm) {
+        const size_t i = (size_t)(rootm - g->local.data());
+        HIP_TRY_G(hipSetDevice(core_device(rootm->core)));
+        hipStream_t s = core_stream(rootm->core);
+        const size_t c = g->h_counts[root];
+        HIP_TRY_G(hipMemcpyAsync((uint32_t *)d_root_offsets + (size_t)root * row, d_offsets[i], row * sizeof(uint32_t),
+                                 hipMemcpyDeviceToDevice, s));
+        if (c) {
+            HIP_TRY_G(hipMemcpyAsync((int32_t *)d_root_xs + base[root], d_xs[i], c * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+            HIP_TRY_G(hipMemcpyAsync((uint8_t *)d_root_diff + base[root], d_diff[i], c, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    return MI355_OK;
+}
+
+}  // extern "C"

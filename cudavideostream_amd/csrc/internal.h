@@ -93,6 +93,14 @@ uint32_t chain_groups(uint32_t ntiles);
 uint32_t chain_capacity(int device);
 hipError_t launch_diff_chain(const ChainArgs &a, uint32_t resident_workgroups, hipStream_t s);
 
+// core.hip, for the other translation units of the library (group.hip)
+}  // namespace mi355
+struct mi355_core;
+namespace mi355 {
+int set_error(int code, const char *what);        // sets the calling thread's mi355_last_error text, returns code
+hipStream_t core_stream(const ::mi355_core *c);   // the stream the core currently enqueues on
+int core_device(const ::mi355_core *c);
+
 // diff_pack.hip
 hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, hipStream_t s);
 uint32_t expand_groups(uint32_t ntiles);

@@ -95,7 +95,27 @@ SYMBOLS = {
     "mi355_get_kernel_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "mi355_reset_timing": (C.c_int, [C.c_void_p]),
+    # multi-GPU (csrc/group.hip)
+    "mi355_group_create": (C.c_int, [C.POINTER(Config), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "mi355_group_unique_id": (C.c_int, [C.c_void_p]),
+    "mi355_group_adopt_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mi355_group_destroy": (None, [C.c_void_p]),
+    "mi355_group_ranks": (C.c_int, [C.c_void_p]),
+    "mi355_group_local_members": (C.c_int, [C.c_void_p]),
+    "mi355_group_core": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "mi355_group_rank_of": (C.c_int, [C.c_void_p, C.c_int]),
+    "mi355_group_diff_stream_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_int,
+                                                C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                C.POINTER(C.c_void_p), C.c_size_t]),
+    "mi355_group_diff_pairs_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                               C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_void_p), C.c_size_t]),
+    "mi355_group_gather": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.POINTER(C.c_uint64)]),
+    "mi355_group_synchronize": (C.c_int, [C.c_void_p]),
 }
+GROUP_ID_BYTES = 128   # MI355_GROUP_ID_BYTES
 
 _lib = None
 

@@ -237,6 +237,48 @@ int mi355_dev_free(mi355_core *core, void *d_ptr);
 int mi355_upload(mi355_core *core, void *d_dst, const void *host_src, size_t bytes);
 int mi355_download(mi355_core *core, void *host_dst, const void *d_src, size_t bytes);
 
+/* ---- multi-GPU: several devices of one node, RCCL over xGMI only for the final changed-pixel gather ------------
+ * The reference runs on one GPU (server/src/kernels.cu:385); this is the sharding BASELINE.json asks of the path
+ * (SURVEY.md section 8e).  The data path has no collective: every member runs an independent stream (E1), its
+ * share of round-robin frame pairs (E1, BASELINE config 5) or a row band of one stream (E2; merge with
+ * mi355_merge_parts on the root's core) through the single-device entry points, side by side.  The one exchange
+ * step is mi355_group_gather.
+ *
+ * A group is either all in this process -- mi355_group_create makes one core per device and an RCCL communicator
+ * over them (a C++ server linked against libmi355compat.a) -- or one member per process: every process creates
+ * its core as usual and calls mi355_group_adopt_rank with the same 128-byte id (made once by
+ * mi355_group_unique_id and handed around by the launcher, e.g. torch.distributed broadcast).  RCCL is bound at
+ * the first group call (dlopen of librccl.so.1); single-GPU users never load it.  The same "one caller thread
+ * at a time" rule as for a core applies to a group. */
+#define MI355_GROUP_ID_BYTES 128
+typedef struct mi355_group mi355_group;
+int mi355_group_create(const mi355_config *cfg, int ndev, const int *devices /* NULL: 0..ndev-1 */,
+                       mi355_group **out);
+int mi355_group_unique_id(void *id128);
+int mi355_group_adopt_rank(mi355_core *core, int nranks, int rank, const void *id128, mi355_group **out);
+void mi355_group_destroy(mi355_group *group);   /* destroys the cores mi355_group_create made, not adopted ones */
+int mi355_group_ranks(const mi355_group *group);           /* members in all processes */
+int mi355_group_local_members(const mi355_group *group);   /* members in this process: 0 <= i < this */
+mi355_core *mi355_group_core(mi355_group *group, int i);   /* member i's core: mi355_set_state etc. */
+int mi355_group_rank_of(const mi355_group *group, int i);  /* member i's rank in the group */
+/* mi355_diff_stream_batch / mi355_diff_pairs_batch on every local member, pointer arrays indexed by local member;
+ * asynchronous on each member's stream. */
+int mi355_group_diff_stream_batch(mi355_group *group, const void *const *d_frames, size_t stride_bytes, int nframes,
+                                  void *const *d_offsets, void *const *d_xs, void *const *d_diff, size_t capacity);
+int mi355_group_diff_pairs_batch(mi355_group *group, const void *const *d_cur, const void *const *d_prev,
+                                 size_t stride_bytes, int nframes, void *const *d_offsets, void *const *d_xs,
+                                 void *const *d_diff, size_t capacity);
+/* Gather-v of the members' batch outputs to rank `root`: collective over ALL ranks of the group (every process
+ * calls it with its local members' arrays).  On the root's device: d_root_offsets[rank][0..nframes] = that
+ * rank's own exclusive scan, d_root_xs / d_root_diff = the ranks' entries back to back in rank order (rank r at
+ * the sum of the counts before it; root_capacity entries).  h_counts[rank] receives every rank's total in every
+ * process (one host synchronisation, kernels.cu:507-508 reads its count back the same way); the transfers
+ * themselves are asynchronous on the members' streams.  d_root_* are ignored where the root is not local. */
+int mi355_group_gather(mi355_group *group, int root, int nframes, const void *const *d_offsets,
+                       const void *const *d_xs, const void *const *d_diff, void *d_root_offsets, void *d_root_xs,
+                       void *d_root_diff, size_t root_capacity, uint64_t *h_counts);
+int mi355_group_synchronize(mi355_group *group);
+
 /* ---- measurement ---------------------------------------------------------------------------------
  * With timing on, every *_batch call brackets its kernels with HIP events on the stream they are
  * launched on.  mi355_get_timing synchronises the stream and returns the sums since the last reset:

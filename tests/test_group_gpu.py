@@ -1,0 +1,107 @@
+"""The multi-GPU entry points of the C-ABI (mi355_group_*, csrc/group.hip) on the GPUs this box has: a group of
+one (or more) devices in one process, and the one-member-per-process form with an RCCL id.  The exchange logic
+for several ranks is the same code path with more peers; its ordering rules are also covered by the gloo tests
+of cudavideostream_amd/gather.py (tests/test_gather_gloo.py)."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cudavideostream_amd import lib, synth
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from cudavideostream_amd.group import CUDAGroup, unique_id  # noqa: E402
+from gpu_util import DEV, CUDACore, to_dev  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def oracle_stream(po, base, frames):
+    return po.diff_stream(frames, base)
+
+
+def test_adopted_rank_gathers_its_own_stream(po):
+    """One member per process (what bench.py does under torch.distributed.run), here a group of one rank."""
+    w, h, T = 96, 54, 7
+    n = 3 * w * h
+    base, frames = synth.webcam_stream(T, w, h, seed=6)
+    eo, exs, edf, est = oracle_stream(po, base, frames)
+    with CUDACore(w, h, max_batch=T, sample_mat_data=base) as core:
+        with CUDAGroup.adopt(core, 1, 0, unique_id()) as grp:
+            assert grp.nranks == 1 and grp.local_members == 1 and grp.rank_of(0) == 0
+            d_fr = to_dev(frames)
+            d_off = torch.zeros(T + 1, dtype=torch.int32, device=DEV)
+            d_xs = torch.full((T * n,), -3, dtype=torch.int32, device=DEV)
+            d_df = torch.zeros(T * n, dtype=torch.uint8, device=DEV)
+            r_off = torch.full((1, T + 1), -1, dtype=torch.int32, device=DEV)
+            r_xs = torch.full((T * n,), -5, dtype=torch.int32, device=DEV)
+            r_df = torch.full((T * n,), 0x77, dtype=torch.uint8, device=DEV)
+            torch.cuda.synchronize()
+            grp.diff_stream_batch([d_fr], T, [d_off], [d_xs], [d_df], T * n, stride=n)
+            counts = grp.gather(0, T, [d_off], [d_xs], [d_df], r_off, r_xs, r_df, T * n)
+            grp.synchronize()
+            tot = int(eo[-1])
+            assert counts.tolist() == [tot]
+            assert np.array_equal(r_off.cpu().numpy().view(np.uint32)[0], eo)
+            assert np.array_equal(r_xs[:tot].cpu().numpy(), exs) and np.array_equal(r_df[:tot].cpu().numpy(), edf)
+            assert (r_xs[tot:tot + 8].cpu().numpy() == -5).all()
+            assert np.array_equal(core.get_state(), est)
+            # capacity below the gathered total is an error, not a truncation
+            with pytest.raises(lib.Mi355Error):
+                grp.gather(0, T, [d_off], [d_xs], [d_df], r_off, r_xs, r_df, tot - 1)
+
+
+def test_group_in_one_process_over_the_visible_devices(po):
+    """mi355_group_create over every GPU of the box (1 on the test box): independent streams, gather to rank 0."""
+    ndev = torch.cuda.device_count()
+    w, h, T = 80, 45, 5
+    n = 3 * w * h
+    L = lib.load()
+    with CUDAGroup.create(w, h, ndev, max_batch=T) as grp:
+        assert grp.nranks == ndev == grp.local_members
+        bufs, want = [], []
+        for r in range(ndev):
+            base, frames = synth.webcam_stream(T, w, h, seed=40 + r)
+            want.append(oracle_stream(po, base, frames))
+            lib.check(L.mi355_set_state(grp.core_handle(r), np.ascontiguousarray(base).ctypes.data))
+            dev = f"cuda:{r}"
+            bufs.append(dict(fr=torch.from_numpy(frames).to(dev), off=torch.zeros(T + 1, dtype=torch.int32, device=dev),
+                             xs=torch.zeros(T * n, dtype=torch.int32, device=dev),
+                             df=torch.zeros(T * n, dtype=torch.uint8, device=dev)))
+        r_off = torch.zeros((ndev, T + 1), dtype=torch.int32, device="cuda:0")
+        r_xs = torch.zeros(ndev * T * n, dtype=torch.int32, device="cuda:0")
+        r_df = torch.zeros(ndev * T * n, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        grp.diff_stream_batch([b["fr"] for b in bufs], T, [b["off"] for b in bufs], [b["xs"] for b in bufs],
+                              [b["df"] for b in bufs], T * n, stride=n)
+        counts = grp.gather(0, T, [b["off"] for b in bufs], [b["xs"] for b in bufs], [b["df"] for b in bufs],
+                            r_off, r_xs, r_df, ndev * T * n)
+        grp.synchronize()
+        at = 0
+        for r in range(ndev):
+            eo, exs, edf, _ = want[r]
+            tot = int(eo[-1])
+            assert int(counts[r]) == tot
+            assert np.array_equal(r_off[r].cpu().numpy().view(np.uint32), eo)
+            assert np.array_equal(r_xs[at:at + tot].cpu().numpy(), exs)
+            assert np.array_equal(r_df[at:at + tot].cpu().numpy(), edf)
+            at += tot
+
+
+GD = os.path.join(ROOT, "tools", "group_demo")
+
+
+@pytest.mark.skipif(not os.path.exists(GD), reason="tools/group_demo not built")
+def test_cpp_group_demo_over_the_c_abi():
+    """tools/group_demo: a g++-only program (no HIP header) drives mi355_group_* and checks the root's copy."""
+    ndev = torch.cuda.device_count()
+    out = subprocess.run([GD, "--ndev", str(ndev), "--width", "320", "--height", "180", "--frames", "6"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["ok"] and r["ndev"] == ndev and r["entries_at_root"] > 0
