@@ -454,6 +454,9 @@ int mi355_set_stream(mi355_core *c, void *hip_stream) {
     if (!c) return fail(MI355_ERR_INVALID, "null core");
     if (int rc = use_device(c)) return rc;
     if (int rc = harvest_timing(c)) return rc;
+    // every batch shares one workspace (log, meta, scans, state): work queued on the old stream must be done
+    // before anything is enqueued on the new one
+    HIP_TRY(hipStreamSynchronize(c->stream));
     c->stream = (hipStream_t)hip_stream;  // NULL is the (legacy) default stream, a valid choice
     return MI355_OK;
 }
@@ -462,6 +465,7 @@ int mi355_use_own_stream(mi355_core *c) {
     if (!c) return fail(MI355_ERR_INVALID, "null core");
     if (int rc = use_device(c)) return rc;
     if (int rc = harvest_timing(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));   // see mi355_set_stream
     c->stream = c->own_stream;
     return MI355_OK;
 }

@@ -260,6 +260,19 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *l
 constexpr uint32_t kXTiles = 64;          // = one wave of k_scan_groups per group
 constexpr uint32_t kScanChunk = 1024;     // groups scanned per pass of k_scan_groups
 
+// The one place where the library orders two agent-scope accesses without a release fence: `*slot = value` must be
+// visible to whoever sees the ticket this call takes.  The store is an agent-scope (write-through) store and the
+// lane waits for its completion (s_waitcnt vmcnt(0): the write has reached the level all XCDs share) before it
+// issues the relaxed ticket increment.  A release fence at agent scope would do the same and also write back this
+// XCD's whole L2, which at this point is full of k_diff_pack's fresh log lines: 19 us instead of 12 us per launch
+// (profiles/README.md).  This leans on gfx950's memory pipeline, not on the HIP memory model; the reader uses
+// agent-scope loads.  Guard: tests/soak.py (15 000 random batches against the oracle, clean).
+__device__ __forceinline__ uint32_t publish_then_take_ticket(uint32_t *slot, uint32_t value, uint32_t *ticket) {
+    __hip_atomic_store(slot, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // grid = T, block = 256: groff[t][g] = flagged bytes of frame t in the groups before g, totals[t] = all
 // of them.  A wave loads the 64 byte counts of a group with one coalesced instruction and reduces them
 // with DPP; the (at most kScanChunk) group sums are scanned in LDS.
@@ -309,16 +322,9 @@ __global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t
         carry += total;
     }
     // totals and the ticket are agent-scope atomics: the workgroups run on different XCDs, whose L2s are
-    // not coherent for plain accesses.  The total is ordered before the ticket by waiting for its store
-    // to complete, not by a release fence -- at agent scope a fence writes back the whole L2, which is full
-    // of k_diff_pack's fresh log lines (measured: 19 us per launch with the fence, see profiles/README.md).
+    // not coherent for plain accesses (publish_then_take_ticket says how the two are ordered).
     __shared__ uint32_t s_is_last;
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&totals[blockIdx.x], carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_is_last = mine == gridDim.x - 1;
-    }
+    if (threadIdx.x == 0) s_is_last = publish_then_take_ticket(&totals[blockIdx.x], carry, ticket) == gridDim.x - 1;
     __syncthreads();
     if (!s_is_last) return;
     const uint32_t nframes = gridDim.x;
@@ -374,6 +380,14 @@ __device__ __forceinline__ void store_u32_unaligned(uint8_t *p, uint32_t v) { __
 // Entries [first, first + count) of a workgroup of NT threads, staged in LDS at s_xs/s_df[0..count), leave with coalesced
 // stores: one dword per index, and the differences as whole dwords too (byte stores only for the up to
 // three bytes before and after the dword-aligned body of the destination).
+// Hand-off between lanes of ONE wave through LDS (k_expand is a single-wave workgroup): the DS operations of a
+// wave execute in order, so this costs nothing in hardware; it keeps the compiler from moving LDS accesses
+// across the hand-off.
+__device__ __forceinline__ void lds_handoff() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <bool WIRE, uint32_t NT>
 __device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint16_t *s_xs, const uint8_t *s_df,
                                               uint32_t first, uint32_t count, uint32_t xs0, uint32_t dst0,
@@ -462,6 +476,7 @@ __global__ __launch_bounds__(64) void k_expand(const ExpandArgs a) {
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
         if ((mk >> lane) & 1) s_src[rx + rank] = (uint16_t)((i << 6) | (uint32_t)lane);
     }
+    lds_handoff();   // s_src is read by other lanes than the ones that wrote it
     const uint32_t xs_base = tile0 * kTileBytes;
     uint32_t carry = 0, flushed = 0;   // entries emitted / already stored
     for (uint32_t base = 0; base < nrec; base += 64) {
@@ -478,7 +493,9 @@ __global__ __launch_bounds__(64) void k_expand(const ExpandArgs a) {
         const uint32_t incl = (uint32_t)wave_inclusive_scan((int)cnt);
         const uint32_t round_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (carry - flushed + round_total > kWStage) {   // wave-uniform: make room
+            lds_handoff();
             flush_entries<WIRE, 64>(a, s_xs, s_df, flushed, carry - flushed, xs_base, dst0, w_xs, w_df, w_room);
+            lds_handoff();   // the stage is rewritten from its start
             flushed = carry;
         }
         uint32_t e = carry - flushed + incl - cnt;        // index in the LDS stage
@@ -516,6 +533,7 @@ __global__ __launch_bounds__(64) void k_expand(const ExpandArgs a) {
             }
         }
     }
+    lds_handoff();
     flush_entries<WIRE, 64>(a, s_xs, s_df, flushed, carry - flushed, xs_base, dst0, w_xs, w_df, w_room);
 }
 

@@ -486,6 +486,16 @@ hipError_t launch_red_stream(uint8_t *out, const uint32_t *offsets, const int32_
 // accumulator, taps in i-major / j-minor order, one multiply then one add per tap.
 // On the interleaved byte image this is a 2-D filter with a horizontal tap spacing of 3 bytes.
 //
+// The store `R[...] = output` of kernels.cu:131-133 converts float to uint8_t: truncation toward zero, and what
+// does not fit saturates (the conversion instruction the reference's compiler emits for it clamps; v_cvt_u32_f32
+// truncates, sends negatives and NaN to 0, and the minimum does the upper clamp).  Both convolution kernels and
+// the oracle use this one definition, so the result does not depend on which kernel a geometry selects.  The
+// server's own kernels are non-negative and normalised: no product sum leaves [0, 255] there.
+__device__ __forceinline__ uint32_t f32_to_u8(float f) {
+    const uint32_t v = (uint32_t)f;
+    return v < 255u ? v : 255u;
+}
+
 __device__ __forceinline__ float byte_f(uint32_t dw, int b) {  // b is a compile-time constant
     return (float)((dw >> (8 * b)) & 0xffu);                   // v_cvt_f32_ubyteN
 }
@@ -598,8 +608,8 @@ void k_conv3x3_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, const
             uint32_t o[NW];
 #pragma unroll
             for (int d = 0; d < NW; d++)
-                o[d] = ((uint32_t)B[2 * d].x & 0xffu) | (((uint32_t)B[2 * d].y & 0xffu) << 8) |
-                       (((uint32_t)B[2 * d + 1].x & 0xffu) << 16) | ((uint32_t)B[2 * d + 1].y << 24);   // :131-133
+                o[d] = f32_to_u8(B[2 * d].x) | (f32_to_u8(B[2 * d].y) << 8) |
+                       (f32_to_u8(B[2 * d + 1].x) << 16) | (f32_to_u8(B[2 * d + 1].y) << 24);   // :131-133
             uint8_t *dst = out + (size_t)(r - 1) * rowbytes + xb;
             if (NW == 4) *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[NW - 2], o[NW - 1]);
             else *reinterpret_cast<uint2 *>(dst) = make_uint2(o[0], o[NW - 1]);
@@ -658,7 +668,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_any(const uint8_t *in, uint8_t 
                 const float prod = sk[i * 3 + j] * (float)tile[ry + i][cb + j * 3];
                 acc = acc + prod;                                  // kernels.cu:126-128
             }
-        out[((size_t)gy * w) * 3 + (size_t)x0 * 3 + cb] = (uint8_t)acc;   // kernels.cu:131-133
+        out[((size_t)gy * w) * 3 + (size_t)x0 * 3 + cb] = (uint8_t)f32_to_u8(acc);   // kernels.cu:131-133
     }
 }
 

@@ -74,7 +74,8 @@ size_t mi355_workspace_bytes(const mi355_core *core);
 
 /* A core starts on a stream of its own.  mi355_set_stream makes it enqueue on an existing hipStream_t
  * instead (e.g. PyTorch's current stream; NULL is the default stream), so that the caller's own work
- * on that stream is ordered with the core's; mi355_use_own_stream goes back. */
+ * on that stream is ordered with the core's; mi355_use_own_stream goes back.  Both wait for the work already
+ * queued on the stream being left (all batches of a core share one workspace). */
 int mi355_set_stream(mi355_core *core, void *hip_stream);
 int mi355_use_own_stream(mi355_core *core);
 int mi355_synchronize(mi355_core *core);
@@ -171,7 +172,9 @@ int mi355_red_overlap(mi355_core *core, void *d_img, const void *d_xs, const voi
  * (NOISE_VISUALIZER 2, kernels.cu:513); clear == 0 paints onto what they hold (NOISE_VISUALIZER 3, :517). */
 int mi355_red_stream_batch(mi355_core *core, const void *d_offsets, const void *d_xs, int nframes,
                            void *d_frames, size_t stride_bytes, int clear);
-/* kernels.cu:97-136: 3x3 convolution with the kernel of mi355_set_conv_kernel; not in-place. */
+/* kernels.cu:97-136: 3x3 convolution with the kernel of mi355_set_conv_kernel; not in-place.  fp32, taps in
+ * i-major / j-minor order, one multiply then one add per tap; the float result is truncated toward zero and
+ * saturated to [0, 255] (any nine floats are accepted: negative taps and sums above 255 clamp). */
 int mi355_conv3x3(mi355_core *core, const void *d_in, void *d_out);
 
 /* tests/noise_filter_benchmark/v3.cu:32-90 (the K = 5 median the reference evaluated and left out of its

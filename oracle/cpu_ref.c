@@ -193,7 +193,9 @@ void ora_conv3x3(const uint8_t *in, uint8_t *out, int w, int h, const float *k) 
                         acc = acc + prod;                        /* ... then add (no FMA) */
                     }
                 }
-                out[((size_t)y * w + x) * 3 + c] = (uint8_t)acc; /* :131-133 truncation */
+                /* :131-133 float -> uint8_t: truncation toward zero; what does not fit saturates (the device
+                 * conversion the reference's store compiles to clamps, a plain C cast would be undefined) */
+                out[((size_t)y * w + x) * 3 + c] = !(acc > 0.0f) ? 0 : acc >= 255.0f ? 255 : (uint8_t)acc;
             }
         }
     }

@@ -177,6 +177,25 @@ def test_median5x5(po, w, h):
             assert (got[t, n:] == 0).all()
 
 
+@pytest.mark.parametrize("w,h", [(16, 30), (65, 17), (352, 95), (7, 5)])
+def test_conv3x3_sharpen_and_edge_kernels_saturate_the_same_way(po, w, h):
+    """Negative taps and sums above 255: the column-strip kernel (row bytes a multiple of 16) and the general
+    one use one conversion (truncate, saturate to [0, 255]), the oracle the same."""
+    rng = np.random.default_rng(w * 3 + h)
+    img = rng.integers(0, 256, 3 * w * h, dtype=np.uint8)
+    kernels = [np.array([0, -1, 0, -1, 5, -1, 0, -1, 0], np.float32),                  # sharpen
+               np.array([-1, -1, -1, -1, 8, -1, -1, -1, -1], np.float32),              # edge
+               np.array([0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5], np.float32),    # gain 4.5
+               np.array([0.1, -0.3, 0.7, 1.1, -0.9, 0.2, 0.6, -0.2, 0.4], np.float32)]
+    for k in kernels:
+        want = po.conv3x3(img, w, h, k)
+        assert (want == 0).any() or (want == 255).any()      # the kernel does leave [0, 255]
+        with CUDACore(w, h, k=k) as core:
+            d_o = dev_out(img.size)
+            core.conv3x3(to_dev(img), d_o); core.synchronize()
+            assert np.array_equal(d_o.cpu().numpy(), want)
+
+
 def test_conv_requires_kernel_and_out_of_place():
     with CUDACore(8, 8) as core:
         d = dev_out(192)
