@@ -75,6 +75,8 @@ struct mi355_core {
     int32_t *one_xs = nullptr;
     uint8_t *one_diff = nullptr;
     int32_t *hist = nullptr, *thr = nullptr;
+    uint8_t *gray1 = nullptr;      // fused gray+binarize chain: one gray byte per pixel of a batch, made on first use
+    size_t gray1_stride = 0;
     float *k9 = nullptr;
     uint8_t *lut = nullptr;
     uint8_t *glyphs = nullptr;
@@ -165,6 +167,13 @@ void build_heat_lut(uint8_t *lut) {
         lut[diff * 3 + 1] = (uint8_t)(int)g;
         lut[diff * 3 + 2] = (uint8_t)(int)r;
     }
+}
+
+// Scratch of the fused gray+binarize chain (one byte per pixel, max_batch frames): made when first needed.
+int need_gray1(mi355_core *c) {
+    if (c->gray1 || c->n == 0) return MI355_OK;
+    c->gray1_stride = ((size_t)c->n / 3 + 15) & ~(size_t)15;
+    return dev_alloc(c, &c->gray1, c->gray1_stride * (size_t)c->cfg.max_batch);
 }
 
 // The one-kernel stream form needs every workgroup resident at once: decided here, once per core.
@@ -437,7 +446,7 @@ void mi355_destroy(mi355_core *c) {
     if (c->nslots) (void)mi355_pipe_close(c);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->meta, c->groff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
-                    c->lut, c->glyphs, c->f_wgsum, c->f_sync, c->f_spill, c->f_ovf, c->f_ready, c->c_desc, c->c_status};
+                    c->lut, c->glyphs, c->gray1, c->f_wgsum, c->f_sync, c->f_spill, c->f_ovf, c->f_ready, c->c_desc, c->c_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_count) (void)hipHostFree(c->h_count);
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -734,9 +743,11 @@ int mi355_filter_batch(mi355_core *c, int op, const void *d_in, const void *d_in
         case MI355_OP_GRAY_WEIGHTED: HIP_TRY(launch_gray(in, out, npix, true, fb, c->stream)); break;
         case MI355_OP_BINARIZE: HIP_TRY(launch_binarize_chain(in, out, c->n, c->hist, c->thr, fb, c->stream)); break;
         case MI355_OP_GRAY_AVG_BINARIZE:
-            HIP_TRY(launch_gray_binarize_fused(in, out, npix, false, c->hist, c->thr, fb, c->stream)); break;
+            if (int rc = need_gray1(c)) return rc;
+            HIP_TRY(launch_gray_binarize_fused(in, out, npix, false, c->hist, c->thr, fb, c->stream, c->gray1, c->gray1_stride)); break;
         case MI355_OP_GRAY_WEIGHTED_BINARIZE:
-            HIP_TRY(launch_gray_binarize_fused(in, out, npix, true, c->hist, c->thr, fb, c->stream)); break;
+            if (int rc = need_gray1(c)) return rc;
+            HIP_TRY(launch_gray_binarize_fused(in, out, npix, true, c->hist, c->thr, fb, c->stream, c->gray1, c->gray1_stride)); break;
         case MI355_OP_HEAT_MAP: HIP_TRY(launch_heat_map(in, in2, out, npix, c->lut, fb, c->stream)); break;
         case MI355_OP_RED_DENSE: HIP_TRY(launch_red_dense(in, in2, out, npix, c->cfg.threshold, fb, c->stream)); break;
         case MI355_OP_CONV3X3: HIP_TRY(launch_conv3x3(in, out, c->cfg.width, c->cfg.height, c->k9, c->k9_sym, fb, c->stream)); break;
@@ -772,7 +783,8 @@ int prepare_frame(mi355_core *c, uint8_t *frame, uint8_t *vis_out, const char *t
     } else if (vis == MI355_VIS_BINARIZE) {
         // grayscale_kernel_v3 + histogram + compute_max + binarize (kernels.cu:493-498), fused: the
         // gray frame is never materialised
-        HIP_TRY(launch_gray_binarize_fused(frame, vis_out, npix, true, c->hist, c->thr, one, s));
+        if (int rc = need_gray1(c)) return rc;
+        HIP_TRY(launch_gray_binarize_fused(frame, vis_out, npix, true, c->hist, c->thr, one, s, c->gray1, c->gray1_stride));
     } else if (vis == MI355_VIS_RED_OVERLAP) {
         // kernels.cu:517 paints onto d_previous, i.e. the state *before* this frame's feedback
         HIP_TRY(hipMemcpyAsync(vis_out, c->state, N, hipMemcpyDeviceToDevice, s));

@@ -157,15 +157,42 @@ hipError_t launch_gray(const uint8_t *in, uint8_t *out, uint32_t npix, bool weig
 constexpr int kHistReplicas = 8;    // private copies of the 256 bins per wave (lane & 7)
 constexpr int kHistBlocks = 4;      // 16-pixel x 256-lane blocks per workgroup (16384 pixels)
 
+// gray1 != nullptr (MODE 1/2): the gray value of every pixel is also kept, one byte per pixel (frame f at
+// gray1 + f * gray1_stride), so that the second pass of the fused chain reads N/3 bytes instead of the colour
+// frame again and does not redo the conversion.
 template <int MODE /*0: gray3 in, 1: colour in + avg, 2: colour in + weighted*/, bool FAST>
 __global__ __launch_bounds__(256) void k_histogram(const uint8_t *img, uint32_t npix, int32_t *hist,
-                                                   size_t stride) {
+                                                   size_t stride, uint8_t *gray1, size_t gray1_stride) {
     __shared__ int32_t bins[4 * kHistReplicas][256];
     img += (size_t)blockIdx.y * stride;
     hist += (size_t)blockIdx.y * 256;
+    if (gray1) gray1 += (size_t)blockIdx.y * gray1_stride;
     for (int i = threadIdx.x; i < 4 * kHistReplicas * 256; i += 256) (&bins[0][0])[i] = 0;
     __syncthreads();
     int32_t *mine = bins[(threadIdx.x >> 6) * kHistReplicas + (threadIdx.x & (kHistReplicas - 1))];
+    // the workgroup's kHistBlocks x 16 pixels per lane are all requested before the first is looked at (the
+    // conversions and LDS atomics of one block then run while the next blocks' bytes are on their way)
+    const uint32_t px0 = (blockIdx.x * kHistBlocks * 256u + threadIdx.x) * 16u;
+    const bool whole = FAST && (blockIdx.x + 1u) * kHistBlocks * 256u * 16u <= npix;   // workgroup-uniform
+    if (whole) {
+        Px16 p[kHistBlocks];
+#pragma unroll
+        for (int it = 0; it < kHistBlocks; it++) p[it] = load_px16<true>(img + (size_t)(px0 + it * 4096u) * 3, 48);
+#pragma unroll
+        for (int it = 0; it < kHistBlocks; it++) {
+            uint32_t gw[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t g = MODE == 0 ? get_byte(p[it], 3 * k)
+                                             : gray_of<MODE == 2>(get_byte(p[it], 3 * k), get_byte(p[it], 3 * k + 1),
+                                                                  get_byte(p[it], 3 * k + 2));
+                atomicAdd(&mine[g], 1);
+                gw[k >> 2] |= g << (8 * (k & 3));
+            }
+            if (MODE != 0 && gray1)
+                *reinterpret_cast<uint4 *>(gray1 + px0 + it * 4096u) = make_uint4(gw[0], gw[1], gw[2], gw[3]);
+        }
+    } else {
 #pragma unroll 1
     for (int it = 0; it < kHistBlocks; it++) {
         const uint32_t lane_px = ((blockIdx.x * kHistBlocks + it) * 256u + threadIdx.x) * 16u;
@@ -174,21 +201,26 @@ __global__ __launch_bounds__(256) void k_histogram(const uint8_t *img, uint32_t 
         const size_t off = (size_t)lane_px * 3;
         if (FAST && rem >= 16) {
             const Px16 p = load_px16<true>(img + off, 48);
+            uint32_t gw[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const uint32_t g = MODE == 0 ? get_byte(p, 3 * k)
                                              : gray_of<MODE == 2>(get_byte(p, 3 * k), get_byte(p, 3 * k + 1),
                                                                   get_byte(p, 3 * k + 2));
                 atomicAdd(&mine[g], 1);
+                gw[k >> 2] |= g << (8 * (k & 3));
             }
+            if (MODE != 0 && gray1) *reinterpret_cast<uint4 *>(gray1 + lane_px) = make_uint4(gw[0], gw[1], gw[2], gw[3]);
         } else {
             const uint32_t cntpx = rem < 16 ? rem : 16;
             for (uint32_t k = 0; k < cntpx; k++) {
                 const uint8_t *q = img + off + 3 * k;
                 const uint32_t g = MODE == 0 ? q[0] : gray_of<MODE == 2>(q[0], q[1], q[2]);
                 atomicAdd(&mine[g], 1);
+                if (MODE != 0 && gray1) gray1[lane_px + k] = (uint8_t)g;
             }
         }
+    }
     }
     __syncthreads();
     int v = 0;
@@ -198,13 +230,18 @@ __global__ __launch_bounds__(256) void k_histogram(const uint8_t *img, uint32_t 
 }
 
 // server.cpp:108-127 executed as written by one lane per frame (256 iterations; dead `else if` kept).
-__global__ void k_two_max_threshold(const int32_t *histogram, int32_t *thr_out) {
-    if (threadIdx.x != 0) return;
+// (The wave first brings the 256 bins into LDS with one coalesced load per lane: the loop's 256 dependent
+// global loads were 20 us per launch, 0.2 us per frame of a 96-frame batch.)
+__global__ __launch_bounds__(64) void k_two_max_threshold(const int32_t *histogram, int32_t *thr_out) {
+    __shared__ int32_t s_hist[256];
     histogram += (size_t)blockIdx.x * 256;
+    for (int i = threadIdx.x; i < 256; i += 64) s_hist[i] = histogram[i];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     int max = -1, sec_max = -1;
     int index_max = -1, index_sec_max = -1;
     for (int i = 0; i < 256; i++) {
-        const int h = histogram[i];
+        const int h = s_hist[i];
         if (h >= max) {
             index_sec_max = index_max;
             index_max = i;
@@ -282,8 +319,42 @@ __global__ __launch_bounds__(256) void k_gray_binarize(const uint8_t *in, uint8_
     }
 }
 
+// Second pass of the fused chain from the kept gray bytes: 16 pixels per lane, one 16-byte load, 48 bytes out
+// (gray > thr ? 255 : 0 in the three channels, kernels.cu:222-241).
+template <bool FAST>
+__global__ __launch_bounds__(256) void k_binarize_gray1(const uint8_t *gray1, size_t gray1_stride, uint8_t *out,
+                                                        uint32_t npix, const int32_t *thr_p, size_t stride) {
+    gray1 += (size_t)blockIdx.y * gray1_stride;
+    out += (size_t)blockIdx.y * stride;
+    const uint32_t thr = (uint32_t)thr_p[blockIdx.y];
+    const uint32_t lane_px = (blockIdx.x * 256u + threadIdx.x) * 16u;
+    if (lane_px >= npix) return;
+    const uint32_t rem = npix - lane_px;
+    const size_t off = (size_t)lane_px * 3;
+    if (FAST && rem >= 16) {
+        const uint4 gv = *reinterpret_cast<const uint4 *>(gray1 + lane_px);
+        const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w};
+        Px16 q;
+#pragma unroll
+        for (int i = 0; i < 12; i++) q.w[i] = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t v = ((gw[k >> 2] >> (8 * (k & 3))) & 0xffu) > thr ? 255u : 0u;
+            put_byte(q, 3 * k, v); put_byte(q, 3 * k + 1, v); put_byte(q, 3 * k + 2, v);
+        }
+        store_px16<true>(out + off, q, 48);
+    } else {
+        const uint32_t cntpx = rem < 16 ? rem : 16;
+        for (uint32_t k = 0; k < cntpx; k++) {
+            const uint8_t v = gray1[lane_px + k] > thr ? 255 : 0;
+            uint8_t *q = out + off + 3 * k;
+            q[0] = v; q[1] = v; q[2] = v;
+        }
+    }
+}
+
 static hipError_t launch_hist_thr(const uint8_t *img, uint32_t npix, int mode, int32_t *hist, int32_t *thr,
-                                  FrameBatch fb, hipStream_t s) {
+                                  FrameBatch fb, hipStream_t s, uint8_t *gray1 = nullptr, size_t gray1_stride = 0) {
     hipError_t e = hipMemsetAsync(hist, 0, (size_t)fb.nframes * 256 * sizeof(int32_t), s);
     if (e != hipSuccess) return e;
     if (npix) {
@@ -292,8 +363,8 @@ static hipError_t launch_hist_thr(const uint8_t *img, uint32_t npix, int mode, i
         const bool fast = aligned16(img) && fb.stride % 16 == 0;
 #define MI355_HIST(M)                                                                                   \
     do {                                                                                                \
-        if (fast) hipLaunchKernelGGL((k_histogram<M, true>), g, dim3(256), 0, s, img, npix, hist, fb.stride); \
-        else hipLaunchKernelGGL((k_histogram<M, false>), g, dim3(256), 0, s, img, npix, hist, fb.stride);     \
+        if (fast) hipLaunchKernelGGL((k_histogram<M, true>), g, dim3(256), 0, s, img, npix, hist, fb.stride, gray1, gray1_stride); \
+        else hipLaunchKernelGGL((k_histogram<M, false>), g, dim3(256), 0, s, img, npix, hist, fb.stride, gray1, gray1_stride);     \
     } while (0)
         if (mode == 0) MI355_HIST(0);
         else if (mode == 1) MI355_HIST(1);
@@ -317,16 +388,26 @@ hipError_t launch_binarize_chain(const uint8_t *gray, uint8_t *out, uint32_t nby
     return hipGetLastError();
 }
 
-// config 3 fused: colour -> (gray, histogram) ; threshold ; colour -> gray -> binarize.  2N read + N
-// write per frame instead of (N+N) + N/3 + (N+N) for the unfused chain.
+// config 3 fused: colour -> (gray, histogram) ; threshold ; gray -> binarize.  With the gray bytes kept
+// (gray1: npix bytes per frame, a multiple of 16 apart): N read + N/3 written, then N/3 read + N written per
+// frame -- 2.67 N; without (gray1 == nullptr): the colour frame is read and converted twice, 3 N.  The unfused
+// chain moves (N+N) + N/3 + (N+N).
 hipError_t launch_gray_binarize_fused(const uint8_t *color, uint8_t *out, uint32_t npix, bool weighted,
-                                      int32_t *hist, int32_t *thr, FrameBatch fb, hipStream_t s) {
+                                      int32_t *hist, int32_t *thr, FrameBatch fb, hipStream_t s, uint8_t *gray1,
+                                      size_t gray1_stride) {
     if (fb.nframes <= 0) return hipSuccess;
-    hipError_t e = launch_hist_thr(color, npix, weighted ? 2 : 1, hist, thr, fb, s);
+    hipError_t e = launch_hist_thr(color, npix, weighted ? 2 : 1, hist, thr, fb, s, gray1, gray1_stride);
     if (e != hipSuccess || npix == 0) return e;
     const bool fast = aligned16(color) && aligned16(out) && fb.stride % 16 == 0;
     dim3 g = px16_grid(npix);
     g.y = (unsigned)fb.nframes;
+    if (gray1) {
+        if (aligned16(out) && fb.stride % 16 == 0)
+            hipLaunchKernelGGL((k_binarize_gray1<true>), g, dim3(256), 0, s, gray1, gray1_stride, out, npix, thr, fb.stride);
+        else
+            hipLaunchKernelGGL((k_binarize_gray1<false>), g, dim3(256), 0, s, gray1, gray1_stride, out, npix, thr, fb.stride);
+        return hipGetLastError();
+    }
     if (weighted) {
         if (fast) hipLaunchKernelGGL((k_gray_binarize<true, true>), g, dim3(256), 0, s, color, out, npix, thr, fb.stride);
         else hipLaunchKernelGGL((k_gray_binarize<true, false>), g, dim3(256), 0, s, color, out, npix, thr, fb.stride);

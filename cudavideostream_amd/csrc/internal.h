@@ -142,7 +142,9 @@ hipError_t launch_gray(const uint8_t *in, uint8_t *out, uint32_t npix, bool weig
 hipError_t launch_binarize_chain(const uint8_t *gray, uint8_t *out, uint32_t nbytes, int32_t *hist,
                                  int32_t *thr, FrameBatch fb, hipStream_t s);
 hipError_t launch_gray_binarize_fused(const uint8_t *color, uint8_t *out, uint32_t npix, bool weighted,
-                                      int32_t *hist, int32_t *thr, FrameBatch fb, hipStream_t s);
+                                      int32_t *hist, int32_t *thr, FrameBatch fb, hipStream_t s,
+                                      uint8_t *gray1 /* scratch: nframes x gray1_stride bytes, or nullptr */,
+                                      size_t gray1_stride /* >= npix, a multiple of 16 */);
 hipError_t launch_heat_map(const uint8_t *cur, const uint8_t *prev, uint8_t *out, uint32_t npix,
                            const uint8_t *lut, FrameBatch fb, hipStream_t s);
 hipError_t launch_red_dense(const uint8_t *cur, const uint8_t *prev, uint8_t *out, uint32_t npix,

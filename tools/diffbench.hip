@@ -6,10 +6,13 @@
 // (tests/test_tools_gpu.py checks the two produce identical bytes).
 //
 //   diffbench [--width W] [--height H] [--batch B] [--steps K] [--warmup W] [--seed S]
-//             [--pairs] [--checksum T]
+//             [--pairs] [--checksum T] [--cores C]
+//   diffbench --filters [--batch B] [--steps K]     the filter kernels and the BASELINE config 3 / 4 chains
+//                                                   (same lines as tools/bench_filters.py, for the --pmc passes)
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -53,7 +56,7 @@ __global__ void k_webcam_frame(uint8_t *out, int t, int width, int height, uint3
 int main(int argc, char **argv) {
     int W = 1920, H = 1080, B = 256, K = 20, WU = 3, checksum_t = -2, ncores = 1;
     uint32_t seed = 21;
-    bool pairs = false;
+    bool pairs = false, filters = false;
     for (int i = 1; i < argc; i++) {
         auto next = [&](int &v) { if (i + 1 < argc) v = atoi(argv[++i]); };
         if (!strcmp(argv[i], "--width")) next(W);
@@ -65,6 +68,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--checksum")) next(checksum_t);
         else if (!strcmp(argv[i], "--pairs")) pairs = true;
         else if (!strcmp(argv[i], "--cores")) next(ncores);
+        else if (!strcmp(argv[i], "--filters")) filters = true;
     }
     const size_t n = (size_t)3 * W * H;
     if (checksum_t >= -1) {  // print a checksum of one generated frame (generator cross-check)
@@ -115,6 +119,59 @@ int main(int argc, char **argv) {
                "\"frames_per_s\": %.1f, \"ms_per_round\": %.4f}\n",
                ncores, B, K, (double)ncores * B * K / sec, sec / K * 1e3);
         for (auto c : cores) mi355_destroy(c);
+        return 0;
+    }
+    if (filters) {   // mi355_filter_batch per kernel, then the two chains; B frames resident, K repetitions each
+        mi355_core *core = nullptr;
+        MI_OK(mi355_create(&cfg, &core));
+        uint8_t *fr, *out, *filt; uint32_t *off; int32_t *xs; uint8_t *df;
+        const size_t cap = (size_t)B * n / 4;
+        HIP_OK(hipMalloc((void **)&fr, n * (size_t)(B + 1)));
+        HIP_OK(hipMalloc((void **)&out, n * (size_t)B));
+        HIP_OK(hipMalloc((void **)&filt, n * (size_t)B));
+        HIP_OK(hipMalloc((void **)&off, sizeof(uint32_t) * (B + 1)));
+        HIP_OK(hipMalloc((void **)&xs, sizeof(int32_t) * cap));
+        HIP_OK(hipMalloc((void **)&df, cap));
+        const dim3 g((unsigned)((n + 255) / 256)), b(256);
+        for (int t = 0; t <= B; t++) hipLaunchKernelGGL(k_webcam_frame, g, b, 0, 0, fr + (size_t)t * n, t - 1, W, H, seed);
+        HIP_OK(hipDeviceSynchronize());
+        std::vector<uint8_t> h_base(n);
+        HIP_OK(hipMemcpy(h_base.data(), fr, n, hipMemcpyDeviceToHost));
+        MI_OK(mi355_set_state(core, h_base.data()));
+        float k9[9];   // a normalised 3x3 Gaussian, sigma 1.5 (symmetric like the server's)
+        { double s = 0; for (int i = 0; i < 9; i++) { const int y = i / 3 - 1, x = i % 3 - 1; k9[i] = (float)exp(-(x * x + y * y) / 4.5); s += k9[i]; }
+          for (float &v : k9) v = (float)(v / s); }
+        MI_OK(mi355_set_conv_kernel(core, k9));
+        const uint8_t *cur = fr + n, *prev = fr;
+        struct Op { const char *name; int op; bool two; double alg; };
+        const double N = (double)n;
+        const Op ops[] = {{"gray_avg", MI355_OP_GRAY_AVG, false, 2 * N}, {"gray_weighted", MI355_OP_GRAY_WEIGHTED, false, 2 * N},
+                          {"gray_weighted+binarize fused (config 3 visualiser)", MI355_OP_GRAY_WEIGHTED_BINARIZE, false, 3 * N},
+                          {"heat_map", MI355_OP_HEAT_MAP, true, 3 * N}, {"red_dense", MI355_OP_RED_DENSE, true, 3 * N},
+                          {"conv3x3", MI355_OP_CONV3X3, false, 2 * N}, {"median5x5", MI355_OP_MEDIAN5X5, false, 2 * N}};
+        auto timed = [&](const char *kind, const char *name, double alg, auto fn) {
+            for (int i = 0; i < 2; i++) fn();
+            MI_OK(mi355_synchronize(core));
+            const auto t0 = std::chrono::high_resolution_clock::now();
+            for (int i = 0; i < K; i++) fn();
+            MI_OK(mi355_synchronize(core));
+            const double us = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count() * 1e6 / ((double)K * B);
+            printf("{\"%s\": \"%s\", \"us_per_frame\": %.3f, \"algorithmic_bytes_per_frame\": %.0f, \"achieved_gbps\": %.1f, \"frac_of_8TBps\": %.4f, \"batch\": %d}\n",
+                   kind, name, us, alg, alg / (us * 1e-6) / 1e9, alg / (us * 1e-6) / 1e9 / 8000.0, B);
+        };
+        for (const Op &o : ops)
+            timed("filter", o.name, o.alg, [&]() { MI_OK(mi355_filter_batch(core, o.op, cur, o.two ? prev : nullptr, out, n, B)); });
+        uint32_t h_tot = 0;
+        timed("chain", "config 3: gray-weighted + binarize + diff/threshold/pack", 4 * N, [&]() {
+            MI_OK(mi355_filter_batch(core, MI355_OP_GRAY_WEIGHTED_BINARIZE, cur, nullptr, out, n, B));
+            MI_OK(mi355_diff_stream_batch(core, cur, n, B, off, xs, df, cap)); });
+        timed("chain", "config 4: noise filter + diff/threshold/pack + red motion map", 5 * N, [&]() {
+            MI_OK(mi355_filter_batch(core, MI355_OP_CONV3X3, cur, nullptr, filt, n, B));
+            MI_OK(mi355_diff_stream_batch(core, filt, n, B, off, xs, df, cap));
+            MI_OK(mi355_red_stream_batch(core, off, xs, B, out, n, 1)); });
+        HIP_OK(hipMemcpy(&h_tot, off + B, sizeof h_tot, hipMemcpyDeviceToHost));
+        printf("{\"note\": \"chains: algorithmic bytes above exclude the 5P of the packed stream\", \"last_chain_changed_bytes_per_frame\": %.1f}\n", (double)h_tot / B);
+        mi355_destroy(core);
         return 0;
     }
     mi355_core *core = nullptr;
