@@ -75,6 +75,7 @@ struct mi355_core {
     int32_t *one_xs = nullptr;
     uint8_t *one_diff = nullptr;
     int32_t *hist = nullptr, *thr = nullptr;
+    uint32_t *red_bounds = nullptr; // mi355_red_stream_batch (cleared form): entry ranges of the frame slices
     uint8_t *gray1 = nullptr;      // fused gray+binarize chain: one gray byte per pixel of a batch, made on first use
     size_t gray1_stride = 0;
     float *k9 = nullptr;
@@ -446,7 +447,7 @@ void mi355_destroy(mi355_core *c) {
     if (c->nslots) (void)mi355_pipe_close(c);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->meta, c->groff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
-                    c->lut, c->glyphs, c->gray1, c->f_wgsum, c->f_sync, c->f_spill, c->f_ovf, c->f_ready, c->c_desc, c->c_status};
+                    c->lut, c->glyphs, c->gray1, c->red_bounds, c->f_wgsum, c->f_sync, c->f_spill, c->f_ovf, c->f_ready, c->c_desc, c->c_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_count) (void)hipHostFree(c->h_count);
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -697,8 +698,11 @@ int mi355_red_stream_batch(mi355_core *c, const void *d_offsets, const void *d_x
     if (!d_offsets || !d_xs || !d_frames) return fail(MI355_ERR_INVALID, "null argument");
     if (stride_bytes < c->n) return fail(MI355_ERR_INVALID, "stride_bytes < frame bytes");
     if (int rc = use_device(c)) return rc;
+    if (nframes > c->cfg.max_batch) return fail(MI355_ERR_INVALID, "nframes outside [0, max_batch]");
+    if (clear && !c->red_bounds)
+        if (int rc = dev_alloc(c, &c->red_bounds, (size_t)c->cfg.max_batch * red_bounds_per_frame(c->n))) return rc;
     HIP_TRY(launch_red_stream((uint8_t *)d_frames, (const uint32_t *)d_offsets, (const int32_t *)d_xs, c->n, clear != 0,
-                              FrameBatch{stride_bytes, nframes}, c->stream));
+                              FrameBatch{stride_bytes, nframes}, c->stream, c->red_bounds));
     return MI355_OK;
 }
 

@@ -549,9 +549,105 @@ __global__ __launch_bounds__(256) void k_red_stream(uint8_t *out, size_t stride,
     }
 }
 
+// The cleared form (NOISE_VISUALIZER 2: memset + red_black_map_overlap, kernels.cu:513-514) in ONE pass that only
+// writes: a workgroup owns a slice of kRedSlice bytes (whole pixels) of one frame, finds the frame's entries that
+// fall into it (the indices of a frame are ascending; k_red_bounds has looked the boundaries up), builds the slice
+// in LDS (zeros, 255 in the red byte of every pixel owning an entry) and stores it with 16-byte stores.
+// N bytes written per frame and nothing else (memset + byte scatter was 2.7 us per 1080p frame).  A workgroup
+// writes kRedSlicesPerBlock consecutive slices.
+constexpr uint32_t kRedSlice = 12288;   // 4096 pixels
+
+// bounds[t][j] = entries of frame t below byte j * kRedSlice * kRedSlicesPerBlock (j = 0 .. blocks per frame):
+// one thread per boundary, a plain binary search (17 dependent probes at 1080p, all boundaries of all frames at
+// once: ~20 us per launch).  Searching inside k_red_stream_clear instead (256-ary, per workgroup) cost 1.8 us
+// per 1080p frame: 6144 workgroups each paying the probes' latency.
+__global__ __launch_bounds__(256) void k_red_bounds(const uint32_t *offsets, const int32_t *xs, uint32_t nbytes,
+                                                    uint32_t per_block, uint32_t nbounds, uint32_t *bounds) {
+    const uint32_t first = offsets[blockIdx.x], n = offsets[blockIdx.x + 1] - first;
+    for (uint32_t j = threadIdx.x; j < nbounds; j += 256) {
+        const uint64_t tgt64 = (uint64_t)j * per_block;
+        const uint32_t target = tgt64 < nbytes ? (uint32_t)tgt64 : nbytes;
+        uint32_t lo = 0, hi = n;                       // lower bound: entries with xs < target
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if ((uint32_t)xs[first + mid] < target) lo = mid + 1;
+            else hi = mid;
+        }
+        bounds[(size_t)blockIdx.x * nbounds + j] = lo;
+    }
+}
+
+// workgroup barrier for hand-offs through LDS only: __syncthreads() also waits for the slice stores in flight
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr uint32_t kRedKeep = 2048;          // entries of a workgroup's range kept in LDS
+constexpr uint32_t kRedSlicesPerBlock = 8;   // slices a workgroup writes one after the other: one search for all of them
+
+__global__ __launch_bounds__(256) void k_red_stream_clear(uint8_t *out, size_t stride, const uint32_t *offsets,
+                                                          const int32_t *xs, uint32_t nbytes, const uint32_t *bounds) {
+    __shared__ uint4 s_slice[kRedSlice / 16];
+    const uint32_t first = offsets[blockIdx.y], n = offsets[blockIdx.y + 1] - first;
+    const uint32_t a0 = blockIdx.x * (kRedSlice * kRedSlicesPerBlock);
+    const uint32_t b0 = min(a0 + kRedSlice * kRedSlicesPerBlock, nbytes);
+    (void)n;
+    const uint32_t *bd = bounds + (size_t)blockIdx.y * (gridDim.x + 1u) + blockIdx.x;
+#if defined(MI355_RED_ABLATE)
+    const uint32_t lo = bd[0], hi = lo + (bd[1] & 0u);    // timing builds only: the bare slice writes
+#else
+    const uint32_t lo = bd[0], hi = bd[1];                // the entries of this workgroup's whole range
+#endif
+    uint8_t *bytes = reinterpret_cast<uint8_t *>(s_slice);
+    // the range's entries come into LDS once (a few hundred on webcam-like input); every slice then looks at all
+    // of them there.  (Re-reading them from global memory for every slice exposed a load latency per slice:
+    // 1.4 us per 1080p frame.)  More than kRedKeep entries (dense frames): read from global memory as needed.
+    __shared__ uint32_t s_ent[kRedKeep];
+    const uint32_t cnt = hi - lo;
+    const bool kept = cnt <= kRedKeep;
+    if (kept)
+        for (uint32_t i = threadIdx.x; i < cnt; i += 256) s_ent[i] = (uint32_t)xs[first + lo + i];
+    for (uint32_t a = a0; a < b0; a += kRedSlice) {
+        const uint32_t b = min(a + kRedSlice, b0);
+        for (uint32_t i = threadIdx.x; i < kRedSlice / 16; i += 256) s_slice[i] = make_uint4(0, 0, 0, 0);
+        lds_only_barrier();
+        // slices are whole pixels: x in [a, b) <=> the painted byte x + (2 - x % 3) in [a, b)  (kernels.cu:273-281)
+        if (kept) {            // workgroup-uniform; two loops so that the LDS form issues no global load at all
+            for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+                const uint32_t x = s_ent[i];
+                if (x >= a && x < b) bytes[x + (2u - x % 3u) - a] = 255;
+            }
+        } else {
+            for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+                const uint32_t x = (uint32_t)xs[first + lo + i];
+                if (x >= a && x < b) bytes[x + (2u - x % 3u) - a] = 255;
+            }
+        }
+        lds_only_barrier();
+        uint8_t *img = out + (size_t)blockIdx.y * stride + a;
+        const uint32_t len = b - a;
+        for (uint32_t i = threadIdx.x; i * 16u < len; i += 256) {
+            if (i * 16u + 16u <= len) *reinterpret_cast<uint4 *>(img + i * 16u) = s_slice[i];
+            else for (uint32_t k = i * 16u; k < len; k++) img[k] = bytes[k];
+        }
+        lds_only_barrier();
+    }
+}
+
+uint32_t red_bounds_per_frame(uint32_t nbytes) {
+    const uint32_t per_block = kRedSlice * kRedSlicesPerBlock;
+    return (nbytes + per_block - 1) / per_block + 1u;
+}
+
 hipError_t launch_red_stream(uint8_t *out, const uint32_t *offsets, const int32_t *xs, uint32_t nbytes, bool clear,
-                             FrameBatch fb, hipStream_t s) {
+                             FrameBatch fb, hipStream_t s, uint32_t *bounds_scratch) {
     if (fb.nframes <= 0 || nbytes == 0) return hipSuccess;
+    if (clear && bounds_scratch && aligned16(out) && fb.stride % 16 == 0) {
+        const uint32_t per_block = kRedSlice * kRedSlicesPerBlock, nb = red_bounds_per_frame(nbytes);
+        hipLaunchKernelGGL(k_red_bounds, dim3((unsigned)fb.nframes), dim3(256), 0, s, offsets, xs, nbytes, per_block, nb,
+                           bounds_scratch);
+        hipLaunchKernelGGL(k_red_stream_clear, dim3(nb - 1u, (unsigned)fb.nframes), dim3(256), 0, s, out, fb.stride,
+                           offsets, xs, nbytes, bounds_scratch);
+        return hipGetLastError();
+    }
     if (clear) {
         hipError_t e = fb.stride == nbytes
                            ? hipMemsetAsync(out, 0, (size_t)fb.nframes * nbytes, s)

@@ -151,8 +151,10 @@ hipError_t launch_red_dense(const uint8_t *cur, const uint8_t *prev, uint8_t *ou
                             int thr, FrameBatch fb, hipStream_t s);
 hipError_t launch_red_overlap(uint8_t *img, const int32_t *xs, const uint32_t *d_count,
                               uint32_t count, uint32_t nbytes, hipStream_t s);
+uint32_t red_bounds_per_frame(uint32_t nbytes);
 hipError_t launch_red_stream(uint8_t *out, const uint32_t *offsets, const int32_t *xs, uint32_t nbytes, bool clear,
-                             FrameBatch fb, hipStream_t s);
+                             FrameBatch fb, hipStream_t s,
+                             uint32_t *bounds_scratch /* nframes x red_bounds_per_frame(nbytes) words, or nullptr */);
 hipError_t launch_conv3x3(const uint8_t *in, uint8_t *out, int w, int h, const float *k9, bool k9_symmetric,
                           FrameBatch fb, hipStream_t s);
 hipError_t launch_median5x5(const uint8_t *in, uint8_t *out, int w, int h, FrameBatch fb, hipStream_t s);

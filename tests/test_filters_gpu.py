@@ -243,6 +243,38 @@ def test_red_stream_batch(po, clear):
             assert np.array_equal(got[t, n:], canvas[t, n:])      # the padding between frames is untouched
 
 
+@pytest.mark.parametrize("w,h", [(640, 360), (1920, 1080), (333, 77)])
+def test_red_stream_clear_many_slices(po, w, h):
+    """The cleared form writes each frame slice by slice from a 256-ary search in the frame's ascending indices:
+    sparse, dense (millions of entries: several search levels), empty and single-entry frames; ragged last slice."""
+    n = 3 * w * h
+    rng = np.random.default_rng(w)
+    base = rng.integers(0, 256, n, dtype=np.uint8)
+    sparse = np.where(rng.random(n) < 0.01, base ^ 0x80, base).astype(np.uint8)
+    dense = synth.refrand_frame(n, 5)
+    one = base.copy(); one[n // 2] ^= 0xFF
+    cur = np.stack([sparse, dense, base, one, base ^ 0x80])
+    prev = np.stack([base, synth.refrand_frame(n, 6), base, base, base])
+    T = cur.shape[0]
+    offs, xs = [0], []
+    for t in range(T):
+        c, x, _, _ = po.diff_pack(cur[t], prev[t])
+        offs.append(offs[-1] + c); xs.append(x)
+    xs = np.concatenate(xs + [np.zeros(1, np.int32)])
+    stride = (n + 15) // 16 * 16 + 16
+    canvas = rng.integers(1, 200, (T, stride), dtype=np.uint8)
+    with CUDACore(w, h, max_batch=T) as core:
+        d_canvas = to_dev(canvas)
+        core.red_stream_batch(to_dev(np.array(offs, np.uint32).view(np.int32)), to_dev(xs), T, d_canvas, clear=True,
+                              stride=stride)
+        core.synchronize()
+        got = d_canvas.cpu().numpy()
+        for t in range(T):
+            want = po.red_overlap(np.zeros(n, np.uint8), xs[offs[t]:offs[t + 1]])
+            assert np.array_equal(got[t, :n], want), t
+            assert np.array_equal(got[t, n:], canvas[t, n:])
+
+
 # ---- exec_core: the per-frame host path (kernels.cu:430-525) ---------------------------------------
 
 def oracle_exec(po, frame, state, vis, k, noise_filter, w, h):

@@ -15,5 +15,6 @@ for v in "$@"; do
   [ -n "${NO_STREAM:-}" ] || for rep in 1 2; do
     echo -n "$name stream: "; LD_LIBRARY_PATH=$d timeout -k 5 120 tools/diffbench --steps 20 ${DIFFBENCH_ARGS:-}
   done
+  [ -z "${FILTERS:-}" ] || { echo "$name filters:"; LD_LIBRARY_PATH=$d timeout -k 5 200 tools/diffbench --filters --batch 96 --steps 5 | grep "${FILTERS}" | cut -c1-170; }
   [ -n "${NO_PAIRS:-}" ] || { echo -n "$name pairs:  "; LD_LIBRARY_PATH=$d timeout -k 5 120 tools/diffbench --steps 20 --pairs ${DIFFBENCH_ARGS:-}; }
 done
