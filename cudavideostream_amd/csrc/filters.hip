@@ -229,33 +229,48 @@ __global__ __launch_bounds__(256) void k_histogram(const uint8_t *img, uint32_t 
     if (v) atomicAdd(&hist[threadIdx.x], v);
 }
 
-// server.cpp:108-127 executed as written by one lane per frame (256 iterations; dead `else if` kept).
-// (The wave first brings the 256 bins into LDS with one coalesced load per lane: the loop's 256 dependent
-// global loads were 20 us per launch, 0.2 us per frame of a 96-frame batch.)
+// server.cpp:108-127, the loop AS CODED on the CPU (the oracle), one wave per frame.  The coded loop keeps the
+// last two bins that were >= every bin before them: on `hist[i] >= max` it shifts index_max into
+// index_sec_max and takes i; its `else if (hist[i] > sec_max && hist[i] < max)` can never fire, because every
+// record sets sec_max = max (simulated on random histograms in tests/test_oracle.py::test_two_max_dead_branch
+// and pinned on the reference's own binary in tests/golden/ref_server_cpu_64x48.npz).  So: bin i is a *record*
+// iff hist[i] >= max(hist[0..i-1]) (the maximum of nothing is -1: bin 0 always is), index_max = the last
+// record, index_sec_max = the record before it (-1 if there is none).  A lane holds 4 consecutive bins; an
+// exclusive max-scan over the lanes (DPP) gives every lane the maximum before its bins.  (Run by one lane as
+// written, the 256 dependent iterations took 20 us per launch.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_max(int v) {
+    return max(v, __builtin_amdgcn_update_dpp(-1, v, CTRL, ROW_MASK, 0xf, false));   // histogram counts are >= 0
+}
+
 __global__ __launch_bounds__(64) void k_two_max_threshold(const int32_t *histogram, int32_t *thr_out) {
-    __shared__ int32_t s_hist[256];
-    histogram += (size_t)blockIdx.x * 256;
-    for (int i = threadIdx.x; i < 256; i += 64) s_hist[i] = histogram[i];
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    int max = -1, sec_max = -1;
-    int index_max = -1, index_sec_max = -1;
-    for (int i = 0; i < 256; i++) {
-        const int h = s_hist[i];
-        if (h >= max) {
-            index_sec_max = index_max;
-            index_max = i;
-            max = h;
-            sec_max = max;
-        } else if (h > sec_max && h < max) {
-            sec_max = h;
-            index_sec_max = i;
-        }
+    const int lane = threadIdx.x;
+    const int4 h = *reinterpret_cast<const int4 *>(histogram + (size_t)blockIdx.x * 256 + 4 * lane);
+    const int b[4] = {h.x, h.y, h.z, h.w};
+    int v = max(max(b[0], b[1]), max(b[2], b[3]));
+    v = dpp_max<0x111, 0xf>(v);  // row_shr:1  -> inclusive max-scan, as wave_inclusive_scan does sums
+    v = dpp_max<0x112, 0xf>(v);
+    v = dpp_max<0x114, 0xf>(v);
+    v = dpp_max<0x118, 0xf>(v);
+    v = dpp_max<0x142, 0xa>(v);  // row_bcast:15
+    v = dpp_max<0x143, 0xc>(v);  // row_bcast:31
+    int before = __builtin_amdgcn_update_dpp(-1, v, 0x138, 0xf, 0xf, false);   // wave_shr:1: the maximum before this lane's bins
+    int top = -1, second = -1;   // this lane's last two records
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (b[k] >= before) { second = top; top = 4 * lane + k; }
+        before = max(before, b[k]);
     }
-    int threshold = (index_max + index_sec_max) / 2;
-    if (threshold < 50) threshold = 50;
+    const uint64_t has = __ballot(top >= 0);          // lane 0 always has bin 0
+    const int l1 = 63 - __builtin_clzll(has);
+    const int index_max = __builtin_amdgcn_readlane(top, l1);
+    int index_sec_max = __builtin_amdgcn_readlane(second, l1);
+    const uint64_t lower = has & ((1ull << l1) - 1ull);
+    if (index_sec_max < 0 && lower) index_sec_max = __builtin_amdgcn_readlane(top, 63 - __builtin_clzll(lower));
+    int threshold = (index_max + index_sec_max) / 2;  // server.cpp:121
+    if (threshold < 50) threshold = 50;               // :122-127
     if (threshold > 200) threshold = 200;
-    thr_out[blockIdx.x] = threshold;
+    if (lane == 0) thr_out[blockIdx.x] = threshold;
 }
 
 // kernels.cu:222-241 / server.cpp:129-135: byte > thr ? 255 : 0, 16 bytes per lane.

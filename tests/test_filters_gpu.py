@@ -104,6 +104,44 @@ def test_binarize_chain_vs_reference_fixture(po):
             assert int(d_thr.item()) == po.two_max_threshold(po.histogram(gray))
 
 
+def test_two_max_threshold_shapes_of_histogram(po):
+    """The threshold kernel finds the last two prefix-maximum records with a wave-wide max-scan; the coded loop of
+    server.cpp:108-127 (the oracle, dead branch included) is sequential.  Histograms built to order: ties,
+    plateaus, strictly rising / falling, a single bin, records at lane boundaries (bins 4k-1, 4k), the clamps."""
+    rng = np.random.default_rng(8)
+    shapes = []
+    shapes.append(np.full(256, 5))                                   # all equal: every bin is a record -> (255+254)/2
+    shapes.append(np.arange(256) + 1)                                # rising
+    shapes.append(256 - np.arange(256))                              # falling: only bin 0 -> (0 + -1)/2 = 0 -> clamp 50
+    one = np.zeros(256, int); one[137] = 9; shapes.append(one)       # bin 0 (count 0) then bin 137
+    for k in (3, 4, 63, 64, 127, 128, 251, 252):
+        v = np.zeros(256, int); v[0] = 3; v[k] = 3; v[min(k + 1, 255)] = 2; shapes.append(v)
+        v = np.zeros(256, int); v[k] = 7; v[k - 1] = 7; shapes.append(v)
+    for _ in range(40):
+        v = rng.integers(0, 6, 256); shapes.append(v)
+        v = np.sort(rng.integers(0, 50, 256)); v[rng.integers(0, 256, 20)] = 0; shapes.append(v)
+    T = len(shapes)
+    npix = max(int(np.max([v.sum() for v in shapes])), 1)
+    w, h = npix, 1
+    n = 3 * npix
+    frames = np.zeros((T, n), np.uint8)
+    for t, v in enumerate(shapes):
+        vals = np.repeat(np.arange(256, dtype=np.uint8), v)
+        pad = np.full(npix - vals.size, vals[0] if vals.size else 0, np.uint8)   # pad with the first value present
+        frames[t] = np.repeat(np.concatenate([vals, pad]), 3)
+    with CUDACore(w, h, max_batch=T) as core:
+        d_out = torch.zeros((T, n), dtype=torch.uint8, device=DEV)
+        core.filter_batch(lib.OP_BINARIZE, to_dev(frames), d_out, T)
+        core.synchronize()
+        got = d_out.cpu().numpy()
+    seen = set()
+    for t in range(T):
+        thr = po.two_max_threshold(po.histogram(frames[t]))
+        seen.add(thr)
+        assert np.array_equal(got[t], po.binarize(frames[t], thr)), (t, thr)
+    assert 50 in seen and 200 in seen and len(seen) >= 5
+
+
 @pytest.mark.parametrize("w,h", [(64, 48), (37, 11), (1920, 1080)])
 def test_binarize_chain_weighted(po, w, h):
     """config 3: weighted gray -> histogram -> two-max -> binarize."""
