@@ -25,6 +25,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -54,7 +55,12 @@ Rccl g_rccl;
 
 int bind_rccl() {
     if (g_rccl.handle) return MI355_OK;
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);   // the copy the process already has, if any
+    // MI355_RCCL_LIB: another library with the same ten entry points (the tests' single-process stand-in, which
+    // lets several ranks share the one GPU of a test box; tests/mock_rccl)
+    const char *other = getenv("MI355_RCCL_LIB");
+    void *h = other && *other ? dlopen(other, RTLD_NOW | RTLD_LOCAL) : nullptr;
+    if (other && *other && !h) return set_error(MI355_ERR_STATE, "MI355_RCCL_LIB is set but cannot be loaded");
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);   // the copy the process already has, if any
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) return set_error(MI355_ERR_STATE, "librccl.so.1 not found: the multi-GPU entry points need RCCL");

@@ -6,6 +6,7 @@ import ctypes as C
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -105,3 +106,76 @@ def test_cpp_group_demo_over_the_c_abi():
     assert out.returncode == 0, out.stderr
     r = json.loads(out.stdout.strip().splitlines()[-1])
     assert r["ok"] and r["ndev"] == ndev and r["entries_at_root"] > 0
+
+
+# ---- several ranks on the one GPU of the test box -------------------------------------------------------------------
+# Real RCCL refuses two ranks on one device.  tests/mock_rccl is a single-process stand-in for the ten RCCL entry
+# points group.hip binds (loaded through MI355_RCCL_LIB, in a child process: the binding is per process): with it
+# the gather-v logic -- counts, rank-ordered places, matching of sends and receives, a root other than 0 -- runs
+# with 2..4 ranks here.  What it cannot show is RCCL's own transport; that is the driver's multi-GPU run.
+MOCK_SRC = os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp")
+MOCK = os.path.join(ROOT, "tests", "mock_rccl", "librccl_mock.so")
+
+
+@pytest.fixture(scope="module")
+def mock_rccl():
+    if not os.path.exists(MOCK) or os.path.getmtime(MOCK) < os.path.getmtime(MOCK_SRC):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", MOCK, MOCK_SRC], check=True)
+    return dict(os.environ, MI355_RCCL_LIB=MOCK)
+
+
+@pytest.mark.skipif(not os.path.exists(GD), reason="tools/group_demo not built")
+@pytest.mark.parametrize("ndev,root", [(2, 0), (2, 1), (3, 1), (4, 3)])
+def test_cpp_group_demo_several_ranks(mock_rccl, ndev, root):
+    out = subprocess.run([GD, "--ndev", str(ndev), "--root", str(root), "--same-device", "1", "--width", "160",
+                          "--height", "90", "--frames", "5"], capture_output=True, text=True, timeout=120, env=mock_rccl)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["ok"] and r["ndev"] == ndev and r["root"] == root and r["entries_at_root"] > 0
+
+
+CHILD = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+from cudavideostream_amd import lib, synth
+from cudavideostream_amd.group import CUDAGroup
+from oracle import pyoracle as po
+ndev, root, w, h, T = 3, 2, 96, 54, 6
+n = 3 * w * h
+L = lib.load()
+with CUDAGroup.create(w, h, ndev, devices=[0] * ndev, max_batch=T) as grp:
+    bufs, want = [], []
+    for r in range(ndev):
+        base, frames = synth.webcam_stream(T, w, h, seed=70 + r)
+        if r == 1:
+            frames = np.repeat(base[None, :], T, axis=0)          # a rank with nothing to send
+        want.append(po.diff_stream(frames, base))
+        lib.check(L.mi355_set_state(grp.core_handle(r), np.ascontiguousarray(base).ctypes.data))
+        bufs.append(dict(fr=torch.from_numpy(np.ascontiguousarray(frames)).cuda(), off=torch.zeros(T + 1, dtype=torch.int32, device="cuda"),
+                         xs=torch.zeros(T * n, dtype=torch.int32, device="cuda"), df=torch.zeros(T * n, dtype=torch.uint8, device="cuda")))
+    r_off = torch.zeros((ndev, T + 1), dtype=torch.int32, device="cuda")
+    r_xs = torch.full((ndev * T * n,), -9, dtype=torch.int32, device="cuda")
+    r_df = torch.zeros(ndev * T * n, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    grp.diff_stream_batch([b["fr"] for b in bufs], T, [b["off"] for b in bufs], [b["xs"] for b in bufs], [b["df"] for b in bufs], T * n, stride=n)
+    counts = grp.gather(root, T, [b["off"] for b in bufs], [b["xs"] for b in bufs], [b["df"] for b in bufs], r_off, r_xs, r_df, ndev * T * n)
+    grp.synchronize()
+    at = 0
+    for r in range(ndev):
+        eo, exs, edf, _ = want[r]
+        tot = int(eo[-1])
+        assert int(counts[r]) == tot, (r, counts, tot)
+        assert np.array_equal(r_off[r].cpu().numpy().view(np.uint32), eo)
+        assert np.array_equal(r_xs[at:at + tot].cpu().numpy(), exs) and np.array_equal(r_df[at:at + tot].cpu().numpy(), edf)
+        at += tot
+    assert int(counts[1]) == 0 and (r_xs[at:at + 4].cpu().numpy() == -9).all()
+print("GROUP-OK")
+"""
+
+
+def test_three_ranks_against_the_oracle(mock_rccl):
+    """Three ranks (one of them with an empty stream), root 2: what arrives at the root, rank by rank, is the oracle's."""
+    code = CHILD % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=mock_rccl, cwd=ROOT)
+    assert out.returncode == 0 and "GROUP-OK" in out.stdout, out.stderr[-2000:]

@@ -6,7 +6,7 @@
 // what that rank produced, the counts add up, and the root's device holds them back to back in rank order.
 // With one GPU (ndev 1) the same calls run and the gather degenerates to the root's own copy.
 //
-//   tools/group_demo [--ndev D] [--width W] [--height H] [--frames T]
+//   tools/group_demo [--ndev D] [--root R] [--width W] [--height H] [--frames T] [--same-device 1]
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -27,9 +27,12 @@ static uint32_t rng_state = 777;
 static uint32_t rnd() { return rng_state = rng_state * 1664525u + 1013904223u; }
 
 int main(int argc, char **argv) {
-    int ndev = 1, W = 320, H = 180, T = 6;
+    int ndev = 1, W = 320, H = 180, T = 6, root = 0;
+    bool same_device = false;   // every rank on device 0: only with a stand-in for RCCL (MI355_RCCL_LIB), see tests/mock_rccl
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--ndev")) ndev = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--root")) root = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--same-device")) same_device = atoi(argv[i + 1]) != 0;
         else if (!strcmp(argv[i], "--width")) W = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--height")) H = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--frames")) T = atoi(argv[i + 1]);
@@ -38,7 +41,8 @@ int main(int argc, char **argv) {
     mi355_config cfg{};
     cfg.width = W; cfg.height = H; cfg.threshold = 20; cfg.max_batch = T; cfg.device = -1;
     mi355_group *grp = nullptr;
-    OK(mi355_group_create(&cfg, ndev, nullptr, &grp));
+    std::vector<int> devs(ndev, 0);
+    OK(mi355_group_create(&cfg, ndev, same_device ? devs.data() : nullptr, &grp));
     if (mi355_group_ranks(grp) != ndev || mi355_group_local_members(grp) != ndev) return 2;
 
     std::vector<void *> d_frames(ndev), d_off(ndev), d_xs(ndev), d_df(ndev);
@@ -65,21 +69,21 @@ int main(int argc, char **argv) {
         OK(mi355_dev_alloc(c, &d_df[r], cap));
         OK(mi355_upload(c, d_frames[r], frames[r].data(), n * T));
     }
-    mi355_core *root = mi355_group_core(grp, 0);
+    mi355_core *root_core = mi355_group_core(grp, root);
     void *r_off = nullptr, *r_xs = nullptr, *r_df = nullptr;
     const size_t rcap = cap * ndev;
-    OK(mi355_dev_alloc(root, &r_off, sizeof(uint32_t) * (T + 1) * ndev));
-    OK(mi355_dev_alloc(root, &r_xs, sizeof(int32_t) * rcap));
-    OK(mi355_dev_alloc(root, &r_df, rcap));
+    OK(mi355_dev_alloc(root_core, &r_off, sizeof(uint32_t) * (T + 1) * ndev));
+    OK(mi355_dev_alloc(root_core, &r_xs, sizeof(int32_t) * rcap));
+    OK(mi355_dev_alloc(root_core, &r_df, rcap));
 
     OK(mi355_group_diff_stream_batch(grp, d_frames.data(), n, T, d_off.data(), d_xs.data(), d_df.data(), cap));
     std::vector<uint64_t> counts(ndev);
-    OK(mi355_group_gather(grp, 0, T, d_off.data(), d_xs.data(), d_df.data(), r_off, r_xs, r_df, rcap, counts.data()));
+    OK(mi355_group_gather(grp, root, T, d_off.data(), d_xs.data(), d_df.data(), r_off, r_xs, r_df, rcap, counts.data()));
     OK(mi355_group_synchronize(grp));
 
     // what the root received against what every rank holds
     std::vector<uint32_t> all_off((size_t)(T + 1) * ndev);
-    OK(mi355_download(root, all_off.data(), r_off, all_off.size() * sizeof(uint32_t)));
+    OK(mi355_download(root_core, all_off.data(), r_off, all_off.size() * sizeof(uint32_t)));
     size_t at = 0;
     uint64_t total = 0;
     for (int r = 0; r < ndev; r++) {
@@ -93,20 +97,20 @@ int main(int argc, char **argv) {
         std::vector<uint8_t> df(cnt), gdf(cnt);
         OK(mi355_download(c, xs.data(), d_xs[r], cnt * sizeof(int32_t)));
         OK(mi355_download(c, df.data(), d_df[r], cnt));
-        OK(mi355_download(root, gxs.data(), (const int32_t *)r_xs + at, cnt * sizeof(int32_t)));
-        OK(mi355_download(root, gdf.data(), (const uint8_t *)r_df + at, cnt));
+        OK(mi355_download(root_core, gxs.data(), (const int32_t *)r_xs + at, cnt * sizeof(int32_t)));
+        OK(mi355_download(root_core, gdf.data(), (const uint8_t *)r_df + at, cnt));
         if (xs != gxs || df != gdf) { fprintf(stderr, "rank %d: payload differs at the root\n", r); return 3; }
         if (cnt == 0) { fprintf(stderr, "rank %d: empty stream, nothing was checked\n", r); return 3; }
         at += cnt;
         total += cnt;
     }
-    printf("{\"tool\": \"group_demo\", \"ndev\": %d, \"width\": %d, \"height\": %d, \"frames\": %d, \"entries_at_root\": %llu, \"ok\": true}\n",
-           ndev, W, H, T, (unsigned long long)total);
+    printf("{\"tool\": \"group_demo\", \"ndev\": %d, \"root\": %d, \"width\": %d, \"height\": %d, \"frames\": %d, \"entries_at_root\": %llu, \"ok\": true}\n",
+           ndev, root, W, H, T, (unsigned long long)total);
     for (int r = 0; r < ndev; r++) {
         mi355_core *c = mi355_group_core(grp, r);
         OK(mi355_dev_free(c, d_frames[r])); OK(mi355_dev_free(c, d_off[r])); OK(mi355_dev_free(c, d_xs[r])); OK(mi355_dev_free(c, d_df[r]));
     }
-    OK(mi355_dev_free(root, r_off)); OK(mi355_dev_free(root, r_xs)); OK(mi355_dev_free(root, r_df));
+    OK(mi355_dev_free(root_core, r_off)); OK(mi355_dev_free(root_core, r_xs)); OK(mi355_dev_free(root_core, r_df));
     mi355_group_destroy(grp);
     return 0;
 }
