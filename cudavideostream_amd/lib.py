@@ -130,6 +130,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch ships its own HIP runtime (libamdhip64 with the system's SONAME).  Whichever copy a process loads
+    # first serves every later user; when this library came first, PyTorch ended up on the system runtime and
+    # the process saw "no ROCm-capable device" (measured: build() then smoke() in one interpreter).  The Python
+    # mirror exists for the tests and bench.py, which hand torch tensors to the library: let torch load first.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # noqa: BLE001  -- a host without PyTorch uses the system runtime, as C++ callers do
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `make -C cudavideostream_amd/csrc` "
