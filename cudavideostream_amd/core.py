@@ -233,6 +233,13 @@ class CUDACore:
         _l.check(self._lib.mi355_binarize_chain(self._h, _ptr(d_gray), _ptr(d_out), _ptr(d_hist),
                                                 _ptr(d_thr)))
 
+    def conv_kxk(self, d_in, d_out, k):
+        """The K x K filter of the reference's filter study (noise_filter_benchmark/v2.cu:36-80); k: K*K floats."""
+        k = np.ascontiguousarray(k, dtype=np.float32).reshape(-1)
+        K = int(round(k.size ** 0.5))
+        assert K * K == k.size
+        _l.check(self._lib.mi355_conv_kxk(self._h, _ptr(d_in), _ptr(d_out), k.ctypes.data, K))
+
     def heat_map(self, d_cur, d_prev, d_out):
         _l.check(self._lib.mi355_heat_map(self._h, _ptr(d_cur), _ptr(d_prev), _ptr(d_out)))
 

@@ -79,6 +79,7 @@ struct mi355_core {
     uint8_t *gray1 = nullptr;      // fused gray+binarize chain: one gray byte per pixel of a batch, made on first use
     size_t gray1_stride = 0;
     float *k9 = nullptr;
+    float *kxk = nullptr;          // mi355_conv_kxk: up to 81 taps, made on first use
     uint8_t *lut = nullptr;
     uint8_t *glyphs = nullptr;
     int nglyphs = 0, glyph_h = 0, glyph_w = 0;
@@ -447,7 +448,7 @@ void mi355_destroy(mi355_core *c) {
     if (c->nslots) (void)mi355_pipe_close(c);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->meta, c->groff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
-                    c->lut, c->glyphs, c->gray1, c->red_bounds, c->f_wgsum, c->f_sync, c->f_spill, c->f_ovf, c->f_ready, c->c_desc, c->c_status};
+                    c->lut, c->glyphs, c->kxk, c->gray1, c->red_bounds, c->f_wgsum, c->f_sync, c->f_spill, c->f_ovf, c->f_ready, c->c_desc, c->c_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_count) (void)hipHostFree(c->h_count);
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -713,6 +714,21 @@ int mi355_conv3x3(mi355_core *c, const void *d_in, void *d_out) {
     if (int rc = use_device(c)) return rc;
     HIP_TRY(launch_conv3x3((const uint8_t *)d_in, (uint8_t *)d_out, c->cfg.width, c->cfg.height, c->k9,
                            c->k9_sym, FrameBatch{c->n, 1}, c->stream));
+    return MI355_OK;
+}
+
+int mi355_conv_kxk(mi355_core *c, const void *d_in, void *d_out, const float *k, int K) {
+    if (!c || !k || (c->n && (!d_in || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
+    if (K < 1 || K > 9) return fail(MI355_ERR_INVALID, "K outside [1, 9]");
+    if (d_in == d_out && c->n) return fail(MI355_ERR_INVALID, "conv_kxk cannot run in place");
+    if (int rc = use_device(c)) return rc;
+    if (!c->kxk)
+        if (int rc = dev_alloc(c, &c->kxk, 81)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));    // a filter of an earlier call may still be reading the taps
+    HIP_TRY(hipMemcpyAsync(c->kxk, k, sizeof(float) * K * K, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));    // k is the caller's (pageable) memory
+    HIP_TRY(launch_conv_kxk((const uint8_t *)d_in, (uint8_t *)d_out, c->cfg.width, c->cfg.height, c->kxk, K,
+                            FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
 }
 

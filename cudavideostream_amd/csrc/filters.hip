@@ -864,6 +864,61 @@ __global__ __launch_bounds__(256) void k_conv3x3_any(const uint8_t *in, uint8_t 
     }
 }
 
+// ---- K x K filter of the reference's filter study: tests/noise_filter_benchmark/v2.cu:36-80 ------------------------
+// The same operator as convolution_kernel above with K = 1..9 (even K included): output (y, x, c) sums
+// k[i*K+j] * in[y - K/2 + i][x - K/2 + j][c] over i (outer) and j (inner), zero outside the image, fp32, one
+// multiply then one add per tap, result truncated and saturated (f32_to_u8).  This is the study's path (it fixes
+// the report's table of residual changes, REPORT/report.tex:2601-2611), not the server's: a lane owns 4 consecutive
+// bytes of a row and reads its taps through the cache (one unaligned dword per tap inside the image, bytes at the
+// borders); no tiling.  K = 3 on the server path is k_conv3x3_strip.
+constexpr int kConvKMax = 9;
+
+__global__ __launch_bounds__(256) void k_conv_kxk(const uint8_t *in, uint8_t *out, int rowbytes, int h, const float *kk,
+                                                  int K, size_t stride) {
+    __shared__ float sk[kConvKMax * kConvKMax];
+    in += (size_t)blockIdx.z * stride;
+    out += (size_t)blockIdx.z * stride;
+    if ((int)threadIdx.x < K * K) sk[threadIdx.x] = kk[threadIdx.x];
+    __syncthreads();
+    const int xb = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xb >= rowbytes || y >= h) return;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int half = K / 2;
+    for (int i = 0; i < K; i++) {
+        const int yy = y - half + i;
+        const bool row_in = yy >= 0 && yy < h;
+        const uint8_t *row = in + (size_t)(row_in ? yy : 0) * rowbytes;
+        for (int j = 0; j < K; j++) {
+            const float kv = sk[i * K + j];
+            const int col = xb + 3 * (j - half);                     // byte column of the tap of output byte xb
+            uint32_t dw = 0;
+            if (row_in) {
+                if (col >= 0 && col + 4 <= rowbytes) __builtin_memcpy(&dw, row + col, 4);
+                else
+                    for (int b = 0; b < 4; b++)
+                        if (col + b >= 0 && col + b < rowbytes) dw |= (uint32_t)row[col + b] << (8 * b);   // zero halo, v2.cu:46-54
+            }
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const float prod = kv * (float)((dw >> (8 * b)) & 0xffu);
+                acc[b] = acc[b] + prod;                               // v2.cu:66-70
+            }
+        }
+    }
+    uint8_t *dst = out + (size_t)y * rowbytes + xb;
+    for (int b = 0; b < 4 && xb + b < rowbytes; b++) dst[b] = (uint8_t)f32_to_u8(acc[b]);
+}
+
+hipError_t launch_conv_kxk(const uint8_t *in, uint8_t *out, int w, int h, const float *kk, int K, FrameBatch fb,
+                           hipStream_t s) {
+    if (w <= 0 || h <= 0 || fb.nframes <= 0) return hipSuccess;
+    const int rowbytes = 3 * w;
+    hipLaunchKernelGGL(k_conv_kxk, dim3((rowbytes + 255) / 256, (h + 3) / 4, (unsigned)fb.nframes), dim3(256), 0, s, in, out,
+                       rowbytes, h, kk, K, fb.stride);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv3x3(const uint8_t *in, uint8_t *out, int w, int h, const float *k9, bool k9_symmetric,
                           FrameBatch fb, hipStream_t s) {
     if (w <= 0 || h <= 0 || fb.nframes <= 0) return hipSuccess;

@@ -176,6 +176,11 @@ int mi355_red_stream_batch(mi355_core *core, const void *d_offsets, const void *
  * i-major / j-minor order, one multiply then one add per tap; the float result is truncated toward zero and
  * saturated to [0, 255] (any nine floats are accepted: negative taps and sums above 255 clamp). */
 int mi355_conv3x3(mi355_core *core, const void *d_in, void *d_out);
+/* The K x K form of the same filter as the reference's filter study runs it, K = 1..9, even K included
+ * (tests/noise_filter_benchmark/v2.cu:36-80: taps at rows / columns -K/2 .. K-1-K/2, zero outside the image); k =
+ * K*K floats in host memory, row-major (v2.cu:116-124 mean, :139-160 Gaussian).  Same arithmetic and conversion as
+ * mi355_conv3x3 (for K = 3 the two agree bit for bit); not in-place; not tuned -- the server's path is K = 3. */
+int mi355_conv_kxk(mi355_core *core, const void *d_in, void *d_out, const float *k, int K);
 
 /* tests/noise_filter_benchmark/v3.cu:32-90 (the K = 5 median the reference evaluated and left out of its
  * server for speed): per channel the median of the 5x5 neighbourhood, zeros outside the image; not in-place. */

@@ -178,6 +178,37 @@ void ora_gaussian_kernel(float *k, int K, float sigma) {
         for (int j = 0; j < K; j++) k[i * K + j] /= sum;         /* :33 */
 }
 
+/* tests/noise_filter_benchmark/v2.cu:116-124 computeMeanKernel: every tap 1.0/(K*K), rounded to float */
+void ora_mean_kernel(float *k, int K) {
+    for (int i = 0; i < K; i++)
+        for (int j = 0; j < K; j++) k[i * K + j] = 1.0 / (K * K);
+}
+
+/* The K x K filter of the reference's filter study, tests/noise_filter_benchmark/v2.cu:36-80 (the same kernel as
+ * server/src/kernels.cu:97-136 with K a compile-time constant 3..9, even K included): output (row_o, col_o) sums
+ * dev_k[i*K+j] * in[row_o - K/2 + i][col_o - K/2 + j] (v2.cu:43-44,66-70), zero outside the image (:46-54; the
+ * halo's third channel is left uninitialised there: not reproduced), float accumulator, i-major / j-minor, one
+ * multiply then one add per tap, float -> uint8_t as ora_conv3x3. */
+void ora_conv_kxk(const uint8_t *in, uint8_t *out, int w, int h, const float *k, int K) {
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            for (int c = 0; c < 3; c++) {
+                float acc = 0.0f;
+                for (int i = 0; i < K; i++) {
+                    for (int j = 0; j < K; j++) {
+                        int yy = y - K / 2 + i, xx = x - K / 2 + j;
+                        float px = (yy >= 0 && yy < h && xx >= 0 && xx < w)
+                                       ? (float)in[((size_t)yy * w + xx) * 3 + c] : 0.0f;
+                        float prod = k[i * K + j] * px;
+                        acc = acc + prod;
+                    }
+                }
+                out[((size_t)y * w + x) * 3 + c] = !(acc > 0.0f) ? 0 : acc >= 255.0f ? 255 : (uint8_t)acc;
+            }
+        }
+    }
+}
+
 void ora_conv3x3(const uint8_t *in, uint8_t *out, int w, int h, const float *k) {
     for (int y = 0; y < h; y++) {
         for (int x = 0; x < w; x++) {

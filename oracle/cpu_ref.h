@@ -60,6 +60,10 @@ void ora_gaussian_kernel(float *k, int K, float sigma);
  * taps i-major/j-minor, one multiply then one add per tap (no FMA contraction), float->u8
  * truncation.  Hard-coded 1920x1080 and the halo channel-2 bug are not reproduced. */
 void ora_conv3x3(const uint8_t *in, uint8_t *out, int w, int h, const float *k);
+/* tests/noise_filter_benchmark/v2.cu:36-80 (K x K, K = 1..9, even K included: taps at -K/2 .. K-1-K/2) and
+ * :116-124 computeMeanKernel; the Gaussian of the study is ora_gaussian_kernel (v2.cu:139-160 == server.cpp:20-36). */
+void ora_conv_kxk(const uint8_t *in, uint8_t *out, int w, int h, const float *k, int K);
+void ora_mean_kernel(float *k, int K);
 /* Secondary oracle, tests/noise_filter_benchmark/cpu.cu:72-98 (int accumulator that truncates
  * after every tap; int images). */
 /* tests/noise_filter_benchmark/v3.cu:32-90: 5x5 median per channel, zeros outside the image. */

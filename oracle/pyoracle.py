@@ -52,6 +52,10 @@ def lib():
     L.ora_gaussian_kernel.argtypes = [f32p, C.c_int, C.c_float]
     L.ora_conv3x3.restype = None
     L.ora_conv3x3.argtypes = [u8p, u8p, C.c_int, C.c_int, f32p]
+    L.ora_conv_kxk.restype = None
+    L.ora_conv_kxk.argtypes = [u8p, u8p, C.c_int, C.c_int, f32p, C.c_int]
+    L.ora_mean_kernel.restype = None
+    L.ora_mean_kernel.argtypes = [f32p, C.c_int]
     L.ora_median5x5.restype = None
     L.ora_median5x5.argtypes = [u8p, u8p, C.c_int, C.c_int]
     L.ora_conv3x3_intacc.restype = None
@@ -174,6 +178,23 @@ def conv3x3(img, w, h, k):
     img = _u8(img)
     out = np.empty_like(img)
     lib().ora_conv3x3(img, out, w, h, np.ascontiguousarray(k, dtype=np.float32))
+    return out
+
+
+def mean_kernel(K):
+    k = np.zeros(K * K, np.float32)
+    lib().ora_mean_kernel(k, K)
+    return k
+
+
+def conv_kxk(img, w, h, k):
+    """tests/noise_filter_benchmark/v2.cu:36-80 with K = sqrt(len(k))."""
+    img = _u8(img)
+    k = np.ascontiguousarray(k, dtype=np.float32).reshape(-1)
+    K = int(round(k.size ** 0.5))
+    assert K * K == k.size
+    out = np.empty_like(img)
+    lib().ora_conv_kxk(img, out, w, h, k, K)
     return out
 
 

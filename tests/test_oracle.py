@@ -108,6 +108,28 @@ def test_f1f2_filter_table(po):
         assert 100.0 * resid / n <= report <= 100.0 * resid_i / n
 
 
+def test_f1f2_whole_filter_table(po):
+    """All nine rows of REPORT/report.tex:2601-2611 (mean K = 3, 5, 7, 9; Gaussian K = 3..7 with its sigma): bytes of
+    the f1/f2 pair still changed after both frames went through the K x K filter of the study
+    (tests/noise_filter_benchmark/v2.cu:36-80 restated as ora_conv_kxk, kernels from v2.cu:116-124 / :139-160).
+    Every row agrees with the report to 0.05 percentage points; even K (4, 6) fixes the tap window -K/2 .. K-1-K/2."""
+    g = golden("ref_f1f2_1080p.npz")
+    f1, f2 = g["f1"], g["f2"]
+    n = f1.size
+    assert list(g["table_report_pct"]) == [3.37, 2.31, 1.66, 1.24, 3.58, 2.87, 2.37, 1.98, 1.66]
+    for kind, K, sigma, pct, want in zip(g["table_kind"], g["table_K"], g["table_sigma"], g["table_report_pct"],
+                                         g["table_resid"]):
+        k = po.mean_kernel(int(K)) if kind == 0 else po.gaussian_kernel(int(K), float(sigma))
+        assert abs(float(k.sum()) - 1.0) < 1e-5
+        a, b = po.conv_kxk(f1, 1920, 1080, k), po.conv_kxk(f2, 1920, 1080, k)
+        resid = po.diff_pack(b, a)[0]
+        assert resid == int(want), (int(K), float(sigma))
+        assert abs(100.0 * resid / n - float(pct)) < 0.05
+    # K = 3 is the server's filter: the general statement and the 3 x 3 one are the same function
+    k3 = po.gaussian_kernel(3, 1.5)
+    assert np.array_equal(po.conv_kxk(f1, 1920, 1080, k3), po.conv3x3(f1, 1920, 1080, k3))
+
+
 def test_two_max_dead_branch(po):
     """server.cpp:116 `else if` can never fire (sec_max == max after every record)."""
     rng = np.random.default_rng(3)

@@ -86,3 +86,48 @@ def test_filter_table(po, pair, name):
         resid = int(off[1])
     assert resid == int(g["resid_" + name])
     assert abs(100.0 * resid / f1.size - float(g["report_pct_" + name])) < 0.05
+
+
+def test_whole_filter_table(po, pair):
+    """REPORT/report.tex:2601-2611, all nine rows, on the GPU: mi355_conv_kxk on both photographs equals the oracle
+    byte for byte, and diff+threshold+pack of the filtered pair counts what the fixture holds (the report's
+    percentages to 0.05 points)."""
+    g, f1, f2 = pair
+    with CUDACore(W, H, max_batch=1) as core:
+        d_f1, d_f2 = to_dev(f1), to_dev(f2)
+        d_a = torch.empty(f1.size, dtype=torch.uint8, device=DEV)
+        d_b = torch.empty(f1.size, dtype=torch.uint8, device=DEV)
+        for kind, K, sigma, pct, want in zip(g["table_kind"], g["table_K"], g["table_sigma"], g["table_report_pct"],
+                                             g["table_resid"]):
+            k = po.mean_kernel(int(K)) if kind == 0 else po.gaussian_kernel(int(K), float(sigma))
+            core.conv_kxk(d_f1, d_a, k)
+            core.conv_kxk(d_f2, d_b, k)
+            core.synchronize()
+            if K in (4, 9):      # the oracle takes seconds per 1080p frame at K = 9: compare bytes for two rows, counts for all
+                assert np.array_equal(d_a.cpu().numpy(), po.conv_kxk(f1, W, H, k)), (int(K), float(sigma))
+            off, _, _, _ = run_stream(core, d_b[None, :], pair_prev=d_a[None, :])
+            assert int(off[1]) == int(want), (int(K), float(sigma))
+            assert abs(100.0 * int(off[1]) / f1.size - float(pct)) < 0.05
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (37, 11), (5, 3), (1, 1), (130, 17)])
+def test_conv_kxk_geometries(po, w, h):
+    """K = 1..9 on small and ragged frames (borders wider than the image included), bit-exact against the oracle;
+    K = 3 equals mi355_conv3x3."""
+    rng = np.random.default_rng(w * 31 + h)
+    img = rng.integers(0, 256, 3 * w * h, dtype=np.uint8)
+    with CUDACore(w, h, k=po.gaussian_kernel(3, 1.5)) as core:
+        d_img = to_dev(img)
+        for K in range(1, 10):
+            for k in (po.mean_kernel(K), po.gaussian_kernel(K, 0.8 + 0.3 * K),
+                      (rng.random(K * K).astype(np.float32) - 0.3).astype(np.float32)):
+                d_o = torch.full((img.size,), 0x5A, dtype=torch.uint8, device=DEV)
+                core.conv_kxk(d_img, d_o, k)
+                core.synchronize()
+                assert np.array_equal(d_o.cpu().numpy(), po.conv_kxk(img, w, h, k)), K
+        d_o = torch.empty(img.size, dtype=torch.uint8, device=DEV)
+        d_p = torch.empty(img.size, dtype=torch.uint8, device=DEV)
+        core.conv_kxk(d_img, d_o, po.gaussian_kernel(3, 1.5))
+        core.conv3x3(d_img, d_p)
+        core.synchronize()
+        assert np.array_equal(d_o.cpu().numpy(), d_p.cpu().numpy())
