@@ -183,6 +183,9 @@ int setup_fused(mi355_core *c) {
     c->fused = false;
     const char *env = getenv("MI355_FUSED");
     if (!(c->cfg.flags & MI355_FLAG_FUSED) && !(env && env[0] == '1')) return MI355_OK;   // opt-in experiment
+#if !MI355_EXPERIMENTS
+    return fail(MI355_ERR_INVALID, "MI355_FLAG_FUSED: this build holds no experiment kernels (make EXPERIMENTS=1)");
+#else
     if (c->n == 0 || c->n % 16u) return MI355_OK;
     c->nwg = (c->ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
     c->fgroups = fused_groups(c->nwg);
@@ -203,6 +206,7 @@ int setup_fused(mi355_core *c) {
     *c->h_status = 0;
     c->fused = true;
     return MI355_OK;
+#endif
 }
 
 // Experiment, opt-in (MI355_FLAG_CHAIN or MI355_CHAIN=1): the pair form as one chained-scan pass
@@ -211,6 +215,9 @@ int setup_chain(mi355_core *c) {
     c->chain = false;
     const char *env = getenv("MI355_CHAIN");
     if (!(c->cfg.flags & MI355_FLAG_CHAIN) && !(env && env[0] == '1')) return MI355_OK;
+#if !MI355_EXPERIMENTS
+    return fail(MI355_ERR_INVALID, "MI355_FLAG_CHAIN: this build holds no experiment kernels (make EXPERIMENTS=1)");
+#else
     if (c->n == 0 || c->n % 16u) return MI355_OK;
     c->cgroups = chain_groups(c->ntiles);
     c->c_resident = chain_capacity(c->device);
@@ -224,8 +231,10 @@ int setup_chain(mi355_core *c) {
     *c->h_cstatus = 0;
     c->chain = true;
     return MI355_OK;
+#endif
 }
 
+#if MI355_EXPERIMENTS
 int run_chain(mi355_core *c, const void *d_cur, const void *d_prev, size_t stride, int nframes, void *d_offsets,
               void *d_xs, void *d_diff, size_t capacity) {
     const size_t T = (size_t)c->cfg.max_batch;
@@ -294,6 +303,7 @@ int run_fused(mi355_core *c, const void *d_cur, size_t stride, int nframes, void
     HIP_TRY(hipMemcpyAsync(c->h_status, c->f_sync, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     return MI355_OK;
 }
+#endif
 
 // d_wire != nullptr: the expander writes the sender's byte stream (capacity in bytes) instead of d_xs/d_diff.
 int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, size_t stride,
@@ -322,6 +332,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
         tev = c->ev[(c->ev_head + c->ev_count) % mi355_core::kEvRing];
         HIP_TRY(hipEventRecord(tev[0], c->stream));
     }
+#if MI355_EXPERIMENTS
     if (c->fused && !pair && !d_wire && (((uintptr_t)d_cur | stride) & 15u) == 0) {
         if (int rc = run_fused(c, d_cur, stride, nframes, d_offsets, d_xs, d_diff, capacity)) return rc;
         if (tev) {
@@ -338,6 +349,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
         }
         return MI355_OK;
     }
+#endif
     PackArgs a{};
     a.cur = (const uint8_t *)d_cur;
     a.prev = (const uint8_t *)d_prev;
@@ -349,6 +361,8 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     a.ntiles = c->ntiles;
     a.rec = c->rec;
     a.meta = c->meta;
+    a.rec_bytes = (uint32_t)((size_t)c->cfg.max_batch * c->ntiles * 1024u);
+    a.meta_bytes = (uint32_t)((size_t)c->cfg.max_batch * c->ntiles * 16u);
     const bool aligned = (((uintptr_t)d_cur | (uintptr_t)d_prev | stride) & 15u) == 0;
     HIP_TRY(launch_diff_pack(a, pair, aligned, c->stream));
     if (tev) HIP_TRY(hipEventRecord(tev[1], c->stream));
@@ -389,7 +403,8 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     const uint64_t n64 = 3ull * (uint64_t)cfg->width * (uint64_t)cfg->height;
     if (n64 >= (1ull << 31)) return fail(MI355_ERR_INVALID, "frame larger than 2 GiB");
     // byte indices are int32 and batch offsets uint32 (the reference's h_xs / h_pos types)
-    if (n64 * (uint64_t)cfg->max_batch >= (1ull << 32))
+    // (whole tiles: the record log, max_batch * ceil(N / 1024) KiB, is addressed with 32-bit byte offsets)
+    if (((n64 + kTileBytes - 1) / kTileBytes * kTileBytes) * (uint64_t)cfg->max_batch >= (1ull << 32))
         return fail(MI355_ERR_INVALID, "max_batch * frame bytes must stay below 2^32");
 
     int ndev = 0;

@@ -42,7 +42,10 @@ namespace mi355 {
 #define MI355_ABLATE 0
 #endif
 
-constexpr int kPrefetch = 4;  // frames per register group (two groups: 8 x 1 KiB in flight per wave)
+#ifndef MI355_K1_PREFETCH
+#define MI355_K1_PREFETCH 4
+#endif
+constexpr int kPrefetch = MI355_K1_PREFETCH;  // frames per register group (two groups: 8 x 1 KiB in flight per wave)
 static_assert(kPrefetch % 2 == 0, "frames are processed in pairs");
 
 // Record log: position `pos` of tile `tile` lives at record index
@@ -168,6 +171,124 @@ __device__ __forceinline__ void pack_group(const PackArgs &a, const Group<PAIR, 
         a.meta[(size_t)(t0 + lane) * a.ntiles + tile] = meta;
 }
 
+// ---- the steady state of the stream loop, written for exact s_waitcnt counts ---------------------------
+// gfx950 has ONE in-order vmcnt for loads and stores.  The compiler can only wait for "all but the N youngest"
+// operations, and N must hold on every path that reaches the wait: a store under a divergent `if` (skipped with
+// s_cbranch_execz when no lane takes it) or a frame loop with `break`s makes N collapse -- the first form of this
+// kernel ended up with `s_waitcnt vmcnt(0)` at the head of its loop (every 8 frames each wave drained its prefetch
+// AND waited for the acknowledgement of the store it had just issued) and with waits that covered the previous
+// group's record stores in front of every frame (ISA in profiles/r03_k1_waitcnt.md).  Here
+//   * the main loop handles only complete groups: no frame-count conditionals inside,
+//   * every record / meta store is a raw buffer store that is ALWAYS issued; lanes with nothing to store carry an
+//     offset beyond the descriptor's range and the hardware drops them (no branch, no traffic),
+//   * frame loads are raw buffer loads through a descriptor rebased per frame (SGPR arithmetic only),
+// so the number of vector-memory operations between a load and its first use is a compile-time constant and the
+// waits are exact: a frame's loads are only ever waited for with the stores of the group before still in flight.
+#ifndef MI355_K1V
+#define MI355_K1V 2
+#endif
+#ifndef MI355_K1_PIN_LOADS
+#define MI355_K1_PIN_LOADS 1
+#endif
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kRsrcWord3 = 0x00020000u;   // raw buffer, 32-bit data format (gfx9 family)
+constexpr uint32_t kOOB = 0xFFFFFFFFu;         // beyond every descriptor's num_records: the lane's store is dropped
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, (int)kRsrcWord3);
+}
+
+template <bool PAIR>
+struct Group2 {
+    uint4 c[kPrefetch];
+    uint4 p[kPrefetch];
+    __device__ __forceinline__ void load(const PackArgs &a, uint32_t voff, int t0) {
+        const int last = a.nframes - 1;
+#pragma unroll
+        for (int d = 0; d < kPrefetch; d++) {
+            const int t = min(t0 + d, last);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.cur + (size_t)t * a.stride, a.n), voff, 0,
+                                                                  PAIR || !MI355_NT_LOADS ? 0 : 2 /* nt */);
+            c[d] = make_uint4(v.x, v.y, v.z, v.w);
+            if (PAIR) {
+                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.prev + (size_t)t * a.stride, a.n), voff, 0, 0);
+                p[d] = make_uint4(w.x, w.y, w.z, w.w);
+            }
+        }
+#if MI355_K1_PIN_LOADS
+        __builtin_amdgcn_sched_barrier(0);   // the loads stay in front of the arithmetic of the other group
+#endif
+    }
+};
+
+// One frame of one full tile: compare, feed back, append the candidates' records at log position `run`.
+__device__ __forceinline__ uint64_t pack_step2(const uint4 c, uint4 &s, ThrConst tc, __amdgpu_buffer_rsrc_t rec,
+                                               uint32_t run, uint32_t tile, uint32_t ntiles, uint32_t &cnt4) {
+    const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+    uint32_t sw[4] = {s.x, s.y, s.z, s.w};
+    uint32_t dm[4], sel[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t x;
+        const uint32_t fh = dword_flags(cw[k], sw[k], tc, x);
+        sel[k] = perm_select(fh);
+        const uint32_t d = bytes_sub_from_x(cw[k], sw[k], x);
+        dm[k] = __builtin_amdgcn_perm(d, 0u, sel[k]);
+        sw[k] = __builtin_amdgcn_perm(cw[k], sw[k], sel[k]);     // negative feedback (kernels.cu:316-331)
+    }
+    s = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+    cnt4 = __builtin_amdgcn_sad_u8(sel[0] + sel[1] + sel[2] + sel[3], 0u, 0u);
+    const bool cand = ((dm[0] | dm[1]) | (dm[2] | dm[3])) != 0u;
+    const uint64_t mask = __ballot(cand);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    // byte offset of log position run + rank (rec_index): the chunk of `run` is wave-uniform, a record that
+    // falls into the next chunk lies (ntiles - 1) KiB further on
+    const uint32_t sbase = (__umul24(run >> 6, ntiles) + tile) * 1024u;             // scalar
+    const uint32_t q = (run & 63u) + rank;
+    const uint32_t off = sbase + q * 16u + (q >= 64u ? (ntiles - 1u) * 1024u : 0u);
+#if MI355_ABLATE == 1 || MI355_ABLATE == 2
+    asm volatile("" ::"v"(dm[0]), "v"(dm[1]), "v"(dm[2]), "v"(dm[3]), "v"(off));
+#else
+    const u32x4 v = {dm[0], dm[1], dm[2], dm[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(v, rec, cand ? off : kOOB, 0, 0);
+#endif
+    return mask;
+}
+
+template <bool PAIR>
+__device__ __forceinline__ void pack_group2(const PackArgs &a, const Group2<PAIR> &g, int t0, uint4 &st, uint32_t &run,
+                                            uint32_t tile, ThrConst tc, int lane, __amdgpu_buffer_rsrc_t rec,
+                                            __amdgpu_buffer_rsrc_t metab) {
+    uint4 meta = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int d = 0; d < kPrefetch; d += 2) {
+        uint32_t c0, c1;
+        if (PAIR) st = g.p[d];
+        const uint32_t run0 = run;
+        const uint64_t m0 = pack_step2(g.c[d], st, tc, rec, run, tile, a.ntiles, c0);
+        run += (uint32_t)__builtin_popcountll(m0);
+        const uint32_t run1 = run;
+        if (PAIR) st = g.p[d + 1];
+        const uint64_t m1 = pack_step2(g.c[d + 1], st, tc, rec, run, tile, a.ntiles, c1);
+        run += (uint32_t)__builtin_popcountll(m1);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane(wave_inclusive_scan((int)(c0 | (c1 << 16))), 63);
+        const uint32_t n0 = ((tot & 0xffffu) - 64u * 24u) >> 2, n1 = ((tot >> 16) - 64u * 24u) >> 2;
+        write_lane(meta.x, (uint32_t)m0, d);
+        write_lane(meta.y, (uint32_t)(m0 >> 32), d);
+        write_lane(meta.z, n0, d);
+        write_lane(meta.w, run0, d);
+        write_lane(meta.x, (uint32_t)m1, d + 1);
+        write_lane(meta.y, (uint32_t)(m1 >> 32), d + 1);
+        write_lane(meta.z, n1, d + 1);
+        write_lane(meta.w, run1, d + 1);
+    }
+#if MI355_ABLATE != 2
+    const uint32_t moff = (__umul24((uint32_t)t0 + (uint32_t)lane, a.ntiles) + tile) * 16u;
+    const u32x4 mv = {meta.x, meta.y, meta.z, meta.w};
+    __builtin_amdgcn_raw_buffer_store_b128(mv, metab, lane < kPrefetch ? moff : kOOB, 0, 0);
+#endif
+}
+
 template <bool PAIR, bool FAST>
 __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint32_t byte_off,
                                           int valid, int lane) {
@@ -176,22 +297,46 @@ __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint
 
     uint4 st = make_uint4(0, 0, 0, 0);
     if (!PAIR) st = load16<FAST>(a.state + byte_off, valid);
-
-    // Two register groups: while one is processed (its stores are issued), the other's loads are in
-    // flight; the next loads are issued right before the wait for the current ones, so the wait is an
-    // exact s_waitcnt vmcnt(kPrefetch).
-    Group<PAIR, FAST> ga, gb;
     uint32_t run = 0;  // records this tile has appended to its log so far
-    ga.load(a, byte_off, 0, valid);
-    for (int t0 = 0;;) {
-        gb.load(a, byte_off, t0 + kPrefetch, valid);
-        pack_group<PAIR, FAST>(a, ga, t0, st, run, tile, tc, lane);
-        t0 += kPrefetch;
-        if (t0 >= T) break;
-        ga.load(a, byte_off, t0 + kPrefetch, valid);
-        pack_group<PAIR, FAST>(a, gb, t0, st, run, tile, tc, lane);
-        t0 += kPrefetch;
-        if (t0 >= T) break;
+    int t0 = 0;
+
+#if MI355_K1V == 2
+    if (FAST) {
+        // complete groups, two per iteration (the register groups swap roles), exact waits (see above)
+        const __amdgpu_buffer_rsrc_t rec = make_rsrc(a.rec, a.rec_bytes);
+        const __amdgpu_buffer_rsrc_t metab = make_rsrc(a.meta, a.meta_bytes);
+        Group2<PAIR> ga, gb;
+        // two groups per round; the first round is peeled so that the loop is entered with exactly the operations
+        // in flight that its back edge carries (the compiler merges the wait counts of both entries to the smaller)
+        auto round = [&]() __attribute__((always_inline)) {
+            gb.load(a, byte_off, t0 + kPrefetch);
+            pack_group2<PAIR>(a, ga, t0, st, run, tile, tc, lane, rec, metab);
+            ga.load(a, byte_off, t0 + 2 * kPrefetch);
+            pack_group2<PAIR>(a, gb, t0 + kPrefetch, st, run, tile, tc, lane, rec, metab);
+            t0 += 2 * kPrefetch;
+        };
+        if (T >= 2 * kPrefetch) {
+            ga.load(a, byte_off, 0);
+            round();
+            while (t0 + 2 * kPrefetch <= T) round();
+        }
+    }
+#endif
+    // the general form: the (up to 2 * kPrefetch - 1) frames the steady state leaves, batches shorter than
+    // that, and ragged tiles
+    if (t0 < T) {
+        Group<PAIR, FAST> ga, gb;
+        ga.load(a, byte_off, t0, valid);
+        for (;;) {
+            gb.load(a, byte_off, t0 + kPrefetch, valid);
+            pack_group<PAIR, FAST>(a, ga, t0, st, run, tile, tc, lane);
+            t0 += kPrefetch;
+            if (t0 >= T) break;
+            ga.load(a, byte_off, t0 + kPrefetch, valid);
+            pack_group<PAIR, FAST>(a, gb, t0, st, run, tile, tc, lane);
+            t0 += kPrefetch;
+            if (t0 >= T) break;
+        }
     }
 
     if (!PAIR) {

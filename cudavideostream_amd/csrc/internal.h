@@ -24,6 +24,8 @@ struct PackArgs {
     uint32_t ntiles;       // W = ceil(n / 1024)
     uint4 *rec;            // record log: T chunks x W tiles x 64 records of 16 masked diff bytes
     uint4 *meta;           // [T][W]: {candidate ballot lo, hi, flagged bytes, log position}
+    uint32_t rec_bytes;    // sizes of the two logs (buffer descriptors of the steady-state loop; both < 2^32)
+    uint32_t meta_bytes;
 };
 
 struct ExpandArgs {

@@ -6,7 +6,7 @@
 // (tests/test_tools_gpu.py checks the two produce identical bytes).
 //
 //   diffbench [--width W] [--height H] [--batch B] [--steps K] [--warmup W] [--seed S]
-//             [--pairs] [--checksum T] [--cores C]
+//             [--pairs] [--checksum T] [--cores C] [--digest]
 //   diffbench --filters [--batch B] [--steps K]     the filter kernels and the BASELINE config 3 / 4 chains
 //                                                   (same lines as tools/bench_filters.py, for the --pmc passes)
 #include <hip/hip_runtime.h>
@@ -56,7 +56,7 @@ __global__ void k_webcam_frame(uint8_t *out, int t, int width, int height, uint3
 int main(int argc, char **argv) {
     int W = 1920, H = 1080, B = 256, K = 20, WU = 3, checksum_t = -2, ncores = 1;
     uint32_t seed = 21;
-    bool pairs = false, filters = false;
+    bool pairs = false, filters = false, digest = false;
     for (int i = 1; i < argc; i++) {
         auto next = [&](int &v) { if (i + 1 < argc) v = atoi(argv[++i]); };
         if (!strcmp(argv[i], "--width")) next(W);
@@ -69,6 +69,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--pairs")) pairs = true;
         else if (!strcmp(argv[i], "--cores")) next(ncores);
         else if (!strcmp(argv[i], "--filters")) filters = true;
+        else if (!strcmp(argv[i], "--digest")) digest = true;
     }
     const size_t n = (size_t)3 * W * H;
     if (checksum_t >= -1) {  // print a checksum of one generated frame (generator cross-check)
@@ -212,6 +213,15 @@ int main(int argc, char **argv) {
     std::vector<uint32_t> off(B + 1);
     HIP_OK(hipMemcpy(off.data(), d_off, sizeof(uint32_t) * (B + 1), hipMemcpyDeviceToHost));
     const double p = off[B];
+    if (digest) {   // order-sensitive digest of everything the batch produced (A/B builds must agree)
+        std::vector<int32_t> hx((size_t)off[B]); std::vector<uint8_t> hd((size_t)off[B]);
+        HIP_OK(hipMemcpy(hx.data(), d_xs, sizeof(int32_t) * hx.size(), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(hd.data(), d_df, hd.size(), hipMemcpyDeviceToHost));
+        uint64_t h = 1469598103934665603ull;
+        for (int t = 0; t <= B; t++) h = (h ^ off[t]) * 1099511628211ull;
+        for (size_t i = 0; i < hx.size(); i++) h = (h ^ ((uint64_t)(uint32_t)hx[i] << 8 | hd[i])) * 1099511628211ull;
+        fprintf(stderr, "digest %016llx\n", (unsigned long long)h);
+    }
     const double pack_ms = ms_pack / (launches ? launches : 1);
     const double alg = 2.0 * n * B + 5.0 * p;
     printf("{\"harness\": \"diffbench\", \"mode\": \"%s\", \"width\": %d, \"height\": %d, \"batch\": %d, \"steps\": %d, "
