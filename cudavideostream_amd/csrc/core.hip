@@ -5,9 +5,10 @@
 //   state     N            the client's reconstructed frame (d_current/d_previous pair of the
 //                          reference collapsed into one persistent buffer)
 //   in, aux, vis  N each   exec(): uploaded frame, filter scratch, visualisation frame
-//   rec       T*W*64*16    record log written by k_diff_pack: 16 masked diff bytes per candidate lane
-//                          (worst case: every lane of every frame), chunk-interleaved over tiles
-//   meta      T*W*16       per (frame, tile): candidate ballot, flagged-byte count, log position
+//   codes     ceil(T/4)*W*1024  code log written by k_diff_pack: 4 bytes per candidate lane (worst case: every lane
+//                          of every frame), chunk-interleaved over tiles
+//   rec       T*W*64*16    record log: 16 masked diff bytes per lane with two or more flagged bytes
+//   meta      T*W*16       per (frame, tile): code position, record position, flagged bytes, candidates | multi << 16
 //   groff     T*ceil(W/64)*4;  totals (T+1)*4 (+ticket);  offsets (T+1)*4
 //   one_xs N*4, one_diff N exec(): packed output of a single frame before the D2H copies
 //   hist T*256*4, thr T*4 (per frame of a filter batch), k9 9*4, heat LUT 766*3, glyph atlas
@@ -22,6 +23,10 @@
 #include "internal.h"
 
 using namespace mi355;
+
+// KiB chunks of one tile's code log: a frame appends at most 64 codes, a chunk holds 256
+// (a frame's codes never straddle chunks: a chunk is left with fewer than 64 free places, i.e. more than 192 used)
+static inline size_t code_chunks(size_t max_batch) { return (max_batch + 2) / 3 + 1; }
 
 namespace {
 
@@ -55,6 +60,7 @@ struct mi355_core {
 
     uint8_t *state = nullptr, *in = nullptr, *aux = nullptr, *vis = nullptr;
     uint4 *rec = nullptr, *meta = nullptr;
+    uint32_t *codes = nullptr;
     uint32_t *groff = nullptr, *totals = nullptr;
     uint32_t *offsets = nullptr;  // T+1, used by exec()
     // one-kernel stream form (diff_fused.hip, opt-in experiment); fused == false: not asked for, or the frame does not fit
@@ -360,6 +366,8 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     a.thr = c->cfg.threshold;
     a.ntiles = c->ntiles;
     a.rec = c->rec;
+    a.codes = c->codes;
+    a.codes_bytes = (uint32_t)(code_chunks((size_t)c->cfg.max_batch) * c->ntiles * 1024u);
     a.meta = c->meta;
     a.rec_bytes = (uint32_t)((size_t)c->cfg.max_batch * c->ntiles * 1024u);
     a.meta_bytes = (uint32_t)((size_t)c->cfg.max_batch * c->ntiles * 16u);
@@ -371,6 +379,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     if (tev) HIP_TRY(hipEventRecord(tev[2], c->stream));
     ExpandArgs g{};
     g.rec = c->rec;
+    g.codes = c->codes;
     g.meta = c->meta;
     g.groff = c->groff;
     g.offsets = (const uint32_t *)d_offsets;
@@ -431,6 +440,7 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (!rc) rc = dev_alloc(c, &c->aux, N + 16);
     if (!rc) rc = dev_alloc(c, &c->vis, N + 16);
     if (!rc) rc = dev_alloc(c, &c->rec, T * W * 64);
+    if (!rc) rc = dev_alloc(c, &c->codes, code_chunks(T) * W * 256);
     if (!rc) rc = dev_alloc(c, &c->meta, T * W);
     if (!rc) rc = dev_alloc(c, &c->groff, T * expand_groups(c->ntiles));
     if (!rc) rc = dev_alloc(c, &c->totals, T + 1);   // + the scan kernel's ticket counter
@@ -462,7 +472,7 @@ void mi355_destroy(mi355_core *c) {
     (void)hipSetDevice(c->device);
     if (c->nslots) (void)mi355_pipe_close(c);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->meta, c->groff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
+    void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->codes, c->meta, c->groff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
                     c->lut, c->glyphs, c->kxk, c->gray1, c->red_bounds, c->f_wgsum, c->f_sync, c->f_spill, c->f_ovf, c->f_ready, c->c_desc, c->c_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_count) (void)hipHostFree(c->h_count);

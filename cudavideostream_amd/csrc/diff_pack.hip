@@ -13,31 +13,28 @@
 //                 the tile's state lives in 4 VGPRs per lane across the batch, so a frame costs N
 //                 bytes of HBM reads instead of 2N; frames are double buffered in two register groups.
 //                 Per frame and dword, 4 bytes at a time (SWAR + v_bitop3 + v_perm):
-//                   flags   9 ops  exact 9-bit compare of 4 bytes (dword_flags)
+//                   flags  10 ops  exact 9-bit compare of 4 bytes (dword_flags)
 //                   select  2 ops  v_perm selector from the flags
 //                   state   1 op   v_perm(cur, state)          negative feedback
 //                   diff    3 ops  per-byte (cur - state), zeroed where un-flagged
-//                   count   3 ops per 16 bytes (sum of the four selectors, v_sad_u8)
-//                 A lane with at least one flagged byte is a *candidate*; candidates are ranked with
-//                 one ballot + mbcnt and each stores its 16 masked diff bytes as ONE 16-byte record
-//                 (un-flagged bytes are 0; a flagged byte is never 0 because |df| > T >= 0).  Records
-//                 of a tile are appended to a chunk-interleaved log (consecutive frames fill whole
-//                 cache lines; all tiles' current chunks are neighbours in memory).  Per (frame, tile)
-//                 one 16-byte meta word keeps {candidate ballot, flagged-byte count, log position}.
+//                   map     1.5 ops (v_dot4 of the flag bytes: 16-bit map of the lane's flagged bytes)
+//                 A lane with at least one flagged byte is a *candidate*: ranked with one ballot + mbcnt
+//                 it appends a 4-byte code {map, the byte's difference, lane} to the tile's code log; a lane
+//                 with two or more flagged bytes also appends its 16 masked difference bytes to the record
+//                 log (see "the log" below).  Per (frame, tile) one 16-byte meta word.
 //   k_scan_groups: per frame, flagged bytes before every group of 64 tiles; its last workgroup scans the
 //               frame totals into offsets[0..T].
-//   k_expand    : one wave per (frame, 16 tiles): turns records into the caller's packed, frame-major,
-//                 ascending (xs, diff) arrays -- or the socket's byte stream -- through an LDS stage
-//                 and coalesced stores.
+//   k_expand    : one wave per (frame, 16 tiles): turns codes and records into the caller's packed,
+//                 frame-major, ascending (xs, diff) arrays -- or the socket's byte stream -- through an
+//                 LDS stage and coalesced stores.
 // No spin waits; the only inter-workgroup communication is the completion ticket of k_scan_groups;
 // results are independent of dispatch order.
 #include "pack_common.h"
 
 namespace mi355 {
 
-// Ablation builds (tools/ablate.sh, never shipped): 1 = no record stores, 2 = also no meta stores,
-// 3 = loads + state fold only (memory floor of the stream loop), 4 / 5 = record store of one lane /
-// of all 64 lanes (bytes vs instruction cost).  0 = the product.
+// Ablation builds (tools/ab_build.sh, never shipped): 1 = no log stores, 2 = also no meta stores,
+// 3 = loads + state fold only (memory floor of the stream loop).  0 = the product.
 #ifndef MI355_ABLATE
 #define MI355_ABLATE 0
 #endif
@@ -48,148 +45,23 @@ namespace mi355 {
 constexpr int kPrefetch = MI355_K1_PREFETCH;  // frames per register group (two groups: 8 x 1 KiB in flight per wave)
 static_assert(kPrefetch % 2 == 0, "frames are processed in pairs");
 
-// Record log: position `pos` of tile `tile` lives at record index
-//   ((pos / 64) * ntiles + tile) * 64 + pos % 64
-// (fits 32 bits: T * W * 64 = max_batch * N / 16 < 2^28; chunk and W are below 2^24)
-__device__ __forceinline__ uint32_t rec_index(uint32_t pos, uint32_t tile, uint32_t ntiles) {
-    return (__umul24(pos >> 6, ntiles) + tile) * 64u + (pos & 63u);
-}
-
-// One frame of one tile: compare, update the state, append the candidate records at log position
-// `run`.  Returns the candidate ballot; cnt4 receives 4 * (this lane's flagged bytes) + 24.
-__device__ __forceinline__ uint64_t pack_step(const uint4 c, uint4 &s, ThrConst tc, uint4 *rec_log,
-                                              uint32_t run, uint32_t tile, uint32_t ntiles,
-                                              uint32_t &cnt4) {
-#if MI355_ABLATE == 3
-    s.x ^= c.x; s.y ^= c.y; s.z ^= c.z; s.w ^= c.w;
-    cnt4 = 24;
-    return 0;
-#endif
-    const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
-    uint32_t sw[4] = {s.x, s.y, s.z, s.w};
-    uint32_t dm[4], sel[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint32_t x;
-        const uint32_t fh = dword_flags(cw[k], sw[k], tc, x);
-        sel[k] = perm_select(fh);
-        const uint32_t d = bytes_sub_from_x(cw[k], sw[k], x);
-        dm[k] = __builtin_amdgcn_perm(d, 0u, sel[k]);            // diff where flagged, 0 elsewhere
-        // negative feedback (kernels.cu:316-331): flagged bytes take the current value, the others
-        // keep the previous one -> the state is the frame the client reconstructs
-        sw[k] = __builtin_amdgcn_perm(cw[k], sw[k], sel[k]);
-    }
-    s = make_uint4(sw[0], sw[1], sw[2], sw[3]);
-    // every selector byte is j + 4*flag: the byte sum of the four selectors is 4*flags + 4*(0+1+2+3)
-    cnt4 = __builtin_amdgcn_sad_u8(sel[0] + sel[1] + sel[2] + sel[3], 0u, 0u);
-
-    const bool cand = ((dm[0] | dm[1]) | (dm[2] | dm[3])) != 0u;
-    const uint64_t mask = __ballot(cand);
-#if MI355_ABLATE >= 1 && MI355_ABLATE < 4
-    asm volatile("" ::"v"(dm[0]), "v"(dm[1]), "v"(dm[2]), "v"(dm[3]));
-#else
-#if MI355_ABLATE == 4   // same instruction stream, 1/19 of the bytes: only the first candidate stores
-    if (cand && __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)) == 0) {
-#elif MI355_ABLATE == 5 // every lane stores (1 KiB per step)
-    if (true) {
-#else
-    if (cand) {
-#endif
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        rec_log[rec_index(run + rank, tile, ntiles)] = make_uint4(dm[0], dm[1], dm[2], dm[3]);
-    }
-#endif
-    return mask;
-}
-
-// A group = kPrefetch consecutive frames of one tile held in registers.  Loads are always issued
-// (frame index clamped to T-1) so that the number of vector-memory operations younger than any
-// load is known at compile time: on gfx950 loads and stores share one in-order vmcnt, and a
-// conditional load would make the compiler fall back to s_waitcnt vmcnt(0) -- i.e. no prefetch.
-template <bool PAIR, bool FAST>
-struct Group {
-    uint4 c[kPrefetch];
-    uint4 p[kPrefetch];
-
-    // The frame base (a.cur + t*stride) is wave-uniform and the lane's byte offset is a 32-bit VGPR:
-    // the loads use the SGPR-base + VGPR-offset form and need no per-lane 64-bit address arithmetic.
-    __device__ __forceinline__ void load(const PackArgs &a, uint32_t byte_off, int t0, int valid) {
-        const int last = a.nframes - 1;
-#pragma unroll
-        for (int d = 0; d < kPrefetch; d++) {
-            const int t = min(t0 + d, last);
-            const uint8_t *cb = uniform_ptr(a.cur + (size_t)t * a.stride);
-            c[d] = load16<FAST, !PAIR>(cb + byte_off, valid);   // stream frames: read once
-            if (PAIR) {
-                const uint8_t *pb = uniform_ptr(a.prev + (size_t)t * a.stride);
-                p[d] = load16<FAST>(pb + byte_off, valid);
-            }
-        }
-    }
-};
-
-template <bool PAIR, bool FAST>
-__device__ __forceinline__ void pack_group(const PackArgs &a, const Group<PAIR, FAST> &g, int t0,
-                                           uint4 &st, uint32_t &run, uint32_t tile, ThrConst tc,
-                                           int lane) {
-    // The group's kPrefetch meta words are assembled in lanes 0..kPrefetch-1 and leave with ONE store.
-    uint4 meta = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int d = 0; d < kPrefetch; d += 2) {
-        const int t = t0 + d;
-        if (t >= a.nframes) break;  // wave-uniform
-        const bool two = t + 1 < a.nframes;
-        // byte counts of the two frames share one register (16-bit fields: a wave total of
-        // 4*flags + 24 per lane is at most 64 * 88 = 5632) and one DPP reduction
-        uint32_t c0 = 24, c1 = 24;
-        if (PAIR) st = g.p[d];
-        const uint32_t run0 = run;
-        const uint64_t m0 = pack_step(g.c[d], st, tc, a.rec, run, tile, a.ntiles, c0);
-        run += (uint32_t)__builtin_popcountll(m0);
-        const uint32_t run1 = run;
-        uint64_t m1 = 0;
-        if (two) {
-            if (PAIR) st = g.p[d + 1];
-            m1 = pack_step(g.c[d + 1], st, tc, a.rec, run, tile, a.ntiles, c1);
-            run += (uint32_t)__builtin_popcountll(m1);
-        }
-        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane(
-            wave_inclusive_scan((int)(c0 | (c1 << 16))), 63);
-        const uint32_t n0 = ((tot & 0xffffu) - 64u * 24u) >> 2, n1 = ((tot >> 16) - 64u * 24u) >> 2;
-        // all four values are wave-uniform: v_writelane drops them into lanes d and d+1
-        write_lane(meta.x, (uint32_t)m0, d);
-        write_lane(meta.y, (uint32_t)(m0 >> 32), d);
-        write_lane(meta.z, n0, d);
-        write_lane(meta.w, run0, d);
-        write_lane(meta.x, (uint32_t)m1, d + 1);
-        write_lane(meta.y, (uint32_t)(m1 >> 32), d + 1);
-        write_lane(meta.z, n1, d + 1);
-        write_lane(meta.w, run1, d + 1);
-    }
-    if (lane < kPrefetch && t0 + lane < a.nframes && MI355_ABLATE != 2 && MI355_ABLATE != 3)
-        a.meta[(size_t)(t0 + lane) * a.ntiles + tile] = meta;
-}
-
-// ---- the steady state of the stream loop, written for exact s_waitcnt counts ---------------------------
-// gfx950 has ONE in-order vmcnt for loads and stores.  The compiler can only wait for "all but the N youngest"
-// operations, and N must hold on every path that reaches the wait: a store under a divergent `if` (skipped with
-// s_cbranch_execz when no lane takes it) or a frame loop with `break`s makes N collapse -- the first form of this
-// kernel ended up with `s_waitcnt vmcnt(0)` at the head of its loop (every 8 frames each wave drained its prefetch
-// AND waited for the acknowledgement of the store it had just issued) and with waits that covered the previous
-// group's record stores in front of every frame (ISA in profiles/r03_k1_waitcnt.md).  Here
-//   * the main loop handles only complete groups: no frame-count conditionals inside,
-//   * every record / meta store is a raw buffer store that is ALWAYS issued; lanes with nothing to store carry an
-//     offset beyond the descriptor's range and the hardware drops them (no branch, no traffic),
-//   * frame loads are raw buffer loads through a descriptor rebased per frame (SGPR arithmetic only),
-// so the number of vector-memory operations between a load and its first use is a compile-time constant and the
-// waits are exact: a frame's loads are only ever waited for with the stores of the group before still in flight.
-#ifndef MI355_K1V
-#define MI355_K1V 2
-#endif
-#ifndef MI355_K1_PIN_LOADS
-#define MI355_K1_PIN_LOADS 1
-#endif
+// ---- the log (round 3) ------------------------------------------------------------------------------
+// What k_diff_pack leaves for k_expand, per (frame, tile):
+//   * one 4-byte CODE per candidate lane (a lane with >= 1 flagged byte), in lane order:
+//         bits  0..15  map of the lane's flagged bytes
+//         bits 16..23  ONE flagged byte: its difference;  more: the lane's rank among the tile's
+//                      multi-byte lanes of this frame (where its record is)
+//         bits 24..29  the lane
+//   * one 16-byte RECORD (the 16 masked difference bytes) per lane with >= 2 flagged bytes,
+//   * one 16-byte meta word {byte offset of the frame's first code, of its first record, flagged bytes,
+//     candidates | multi-byte lanes << 16}.
+// On webcam-like input (isolated bytes) 84 % of the candidates carry one byte: the log shrinks from 16 to
+// 4 + 0.16 * 16 = 6.6 bytes per candidate, and the expander neither rebuilds the byte maps nor searches for the
+// lane a record came from.  Both logs are chunk-interleaved: chunk k of tile `tile` is the KiB at
+// (k * ntiles + tile) * 1024 (every tile appends sequentially; all tiles' current chunks are neighbours in
+// memory); a chunk holds 256 codes or 64 records, and a frame's units never straddle two chunks (LogPos).
+// Stores are raw buffer stores that are always issued: a lane with nothing to store carries an offset beyond
+// the descriptor's range and the hardware drops it (no branch around the store, no traffic).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t kRsrcWord3 = 0x00020000u;   // raw buffer, 32-bit data format (gfx9 family)
 constexpr uint32_t kOOB = 0xFFFFFFFFu;         // beyond every descriptor's num_records: the lane's store is dropped
@@ -198,94 +70,145 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint3
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, (int)kRsrcWord3);
 }
 
-template <bool PAIR>
-struct Group2 {
+struct LogOut {
+    __amdgpu_buffer_rsrc_t codes, recs, meta;
+};
+
+// One frame of one tile, arithmetic only: compare, feed back.  dm = the 16 masked difference bytes,
+// m16 = map of the flagged bytes.
+__device__ __forceinline__ void compare_step(const uint4 c, uint4 &s, ThrConst tc, uint32_t (&dm)[4], uint32_t &m16) {
+    const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+    uint32_t sw[4] = {s.x, s.y, s.z, s.w};
+    uint32_t fh[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#if MI355_ABLATE == 3
+        sw[k] ^= cw[k]; dm[k] = 0; fh[k] = 0;
+#else
+        uint32_t x;
+        fh[k] = dword_flags(cw[k], sw[k], tc, x);
+        // 0xFF in every flagged byte: a v_perm selector byte of 0x80 yields the constant 0xFF, one of 0x00
+        // byte 0 of the second operand (0)
+        const uint32_t mask = __builtin_amdgcn_perm(0u, 0u, fh[k]);
+        dm[k] = bytes_sub_from_x(cw[k], sw[k], x) & mask;     // diff where flagged, 0 elsewhere
+        // negative feedback (kernels.cu:316-331): flagged bytes take the current value, the others
+        // keep the previous one -> the state is the frame the client reconstructs
+        sw[k] = bitop3<(TA & TC) | (TB & ~TC)>(cw[k], sw[k], mask);
+#endif
+    }
+    s = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+    // flags are 0x80 per flagged byte: two v_dot4 chains weigh them into 128 * (map of 8 bytes)
+    const uint32_t lo = __builtin_amdgcn_udot4(fh[1], 0x80402010u, __builtin_amdgcn_udot4(fh[0], 0x08040201u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(fh[3], 0x80402010u, __builtin_amdgcn_udot4(fh[2], 0x08040201u, 0u, false), false);
+    m16 = (lo + (hi << 8)) >> 7;
+}
+
+// Where the tile's next code / record goes (wave-uniform, SGPRs): byte offset into the log and units left in
+// the current KiB chunk.  A frame's codes (records) never straddle a chunk: if they do not fit, the rest of the
+// chunk is skipped (the next chunk of the same tile lies `jump` = (ntiles - 1) KiB behind the end of this one),
+// so a frame's units are contiguous and k_expand addresses them with the byte offset kept in the meta word.
+struct LogPos {
+    uint32_t ptrC, roomC, ptrM, roomM;
+};
+
+// Appends the frame's codes and records; pc / pm = byte offsets of its first code / record; returns
+// candidates | multi-byte lanes << 16.
+__device__ __forceinline__ uint32_t emit_step(const uint32_t (&dm)[4], uint32_t m16, const LogOut &lg, LogPos &lp,
+                                              uint32_t jump, uint32_t lane24, uint32_t &pc, uint32_t &pm) {
+    const bool cand = m16 != 0u;
+    const bool multi = (m16 & (m16 - 1u)) != 0u;
+    const uint64_t bc = __ballot(cand), bm = __ballot(multi);
+    const uint32_t rankC = __builtin_amdgcn_mbcnt_hi((uint32_t)(bc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bc, 0u));
+    const uint32_t rankM = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+    const uint32_t nc = (uint32_t)__builtin_popcountll(bc), nm = (uint32_t)__builtin_popcountll(bm);
+    if (nc > lp.roomC) { lp.ptrC += lp.roomC * 4u + jump; lp.roomC = 256u; }
+    if (nm > lp.roomM) { lp.ptrM += lp.roomM * 16u + jump; lp.roomM = 64u; }
+    pc = lp.ptrC;
+    pm = lp.ptrM;
+    // a lane with one flagged byte: the byte sum of its masked differences IS that byte
+    const uint32_t one = __builtin_amdgcn_sad_u8((dm[0] | dm[1]) | (dm[2] | dm[3]), 0u, 0u);
+    const uint32_t code = m16 | ((multi ? rankM : one) << 16) | lane24;
+#if MI355_ABLATE == 0
+    __builtin_amdgcn_raw_buffer_store_b32(code, lg.codes, cand ? pc + rankC * 4u : kOOB, 0, 0);
+    const u32x4 v = {dm[0], dm[1], dm[2], dm[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(v, lg.recs, multi ? pm + rankM * 16u : kOOB, 0, 0);
+#else
+    asm volatile("" ::"v"(dm[0]), "v"(dm[1]), "v"(dm[2]), "v"(dm[3]), "v"(rankC), "v"(rankM), "v"(code));
+#endif
+    lp.ptrC += nc * 4u;
+    lp.roomC -= nc;
+    lp.ptrM += nm * 16u;
+    lp.roomM -= nm;
+    return nc | (nm << 16);
+}
+
+// A group = kPrefetch consecutive frames of one tile held in registers.  Loads are always issued
+// (frame index clamped to T-1): on gfx950 loads and stores share one in-order vmcnt, and a conditional
+// load makes the compiler fall back to s_waitcnt vmcnt(0) -- i.e. no prefetch.
+template <bool PAIR, bool FAST>
+struct Group {
     uint4 c[kPrefetch];
     uint4 p[kPrefetch];
-    __device__ __forceinline__ void load(const PackArgs &a, uint32_t voff, int t0) {
+
+    // The frame bases are wave-uniform (SGPRs) and the lane's byte offset is a 32-bit VGPR: the loads use the
+    // SGPR-base + VGPR-offset form.  `cur0` / `prev0` point at frame t0; frames beyond the batch repeat the last one.
+    __device__ __forceinline__ void load(const PackArgs &a, uint32_t byte_off, int t0, int valid, const uint8_t *cur0,
+                                         const uint8_t *prev0, const uint8_t *cur_last, const uint8_t *prev_last) {
         const int last = a.nframes - 1;
 #pragma unroll
         for (int d = 0; d < kPrefetch; d++) {
-            const int t = min(t0 + d, last);
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.cur + (size_t)t * a.stride, a.n), voff, 0,
-                                                                  PAIR || !MI355_NT_LOADS ? 0 : 2 /* nt */);
-            c[d] = make_uint4(v.x, v.y, v.z, v.w);
+            const bool in = t0 + d <= last;
+            const uint8_t *cb = uniform_ptr(in ? cur0 + (size_t)d * a.stride : cur_last);
+            c[d] = load16<FAST, !PAIR>(cb + byte_off, valid);   // stream frames: read once
             if (PAIR) {
-                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.prev + (size_t)t * a.stride, a.n), voff, 0, 0);
-                p[d] = make_uint4(w.x, w.y, w.z, w.w);
+                const uint8_t *pb = uniform_ptr(in ? prev0 + (size_t)d * a.stride : prev_last);
+                p[d] = load16<FAST>(pb + byte_off, valid);
             }
         }
-#if MI355_K1_PIN_LOADS
-        __builtin_amdgcn_sched_barrier(0);   // the loads stay in front of the arithmetic of the other group
-#endif
     }
 };
 
-// One frame of one full tile: compare, feed back, append the candidates' records at log position `run`.
-__device__ __forceinline__ uint64_t pack_step2(const uint4 c, uint4 &s, ThrConst tc, __amdgpu_buffer_rsrc_t rec,
-                                               uint32_t run, uint32_t tile, uint32_t ntiles, uint32_t &cnt4) {
-    const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
-    uint32_t sw[4] = {s.x, s.y, s.z, s.w};
-    uint32_t dm[4], sel[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint32_t x;
-        const uint32_t fh = dword_flags(cw[k], sw[k], tc, x);
-        sel[k] = perm_select(fh);
-        const uint32_t d = bytes_sub_from_x(cw[k], sw[k], x);
-        dm[k] = __builtin_amdgcn_perm(d, 0u, sel[k]);
-        sw[k] = __builtin_amdgcn_perm(cw[k], sw[k], sel[k]);     // negative feedback (kernels.cu:316-331)
-    }
-    s = make_uint4(sw[0], sw[1], sw[2], sw[3]);
-    cnt4 = __builtin_amdgcn_sad_u8(sel[0] + sel[1] + sel[2] + sel[3], 0u, 0u);
-    const bool cand = ((dm[0] | dm[1]) | (dm[2] | dm[3])) != 0u;
-    const uint64_t mask = __ballot(cand);
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    // byte offset of log position run + rank (rec_index): the chunk of `run` is wave-uniform, a record that
-    // falls into the next chunk lies (ntiles - 1) KiB further on
-    const uint32_t sbase = (__umul24(run >> 6, ntiles) + tile) * 1024u;             // scalar
-    const uint32_t q = (run & 63u) + rank;
-    const uint32_t off = sbase + q * 16u + (q >= 64u ? (ntiles - 1u) * 1024u : 0u);
-#if MI355_ABLATE == 1 || MI355_ABLATE == 2
-    asm volatile("" ::"v"(dm[0]), "v"(dm[1]), "v"(dm[2]), "v"(dm[3]), "v"(off));
-#else
-    const u32x4 v = {dm[0], dm[1], dm[2], dm[3]};
-    __builtin_amdgcn_raw_buffer_store_b128(v, rec, cand ? off : kOOB, 0, 0);
-#endif
-    return mask;
-}
-
-template <bool PAIR>
-__device__ __forceinline__ void pack_group2(const PackArgs &a, const Group2<PAIR> &g, int t0, uint4 &st, uint32_t &run,
-                                            uint32_t tile, ThrConst tc, int lane, __amdgpu_buffer_rsrc_t rec,
-                                            __amdgpu_buffer_rsrc_t metab) {
+template <bool PAIR, bool FAST>
+__device__ __forceinline__ void pack_group(const PackArgs &a, const Group<PAIR, FAST> &g, int t0, uint4 &st,
+                                           LogPos &lp, uint32_t tile, ThrConst tc, int lane, const LogOut &lg) {
+    // The group's kPrefetch meta words are assembled in lanes 0..kPrefetch-1 and leave with ONE store.
     uint4 meta = make_uint4(0, 0, 0, 0);
+    const uint32_t lane24 = (uint32_t)lane << 24;
+    const uint32_t jump = (a.ntiles - 1u) * 1024u;
 #pragma unroll
     for (int d = 0; d < kPrefetch; d += 2) {
-        uint32_t c0, c1;
+        const int t = t0 + d;
+        if (t >= a.nframes) break;  // wave-uniform
+        const bool two = t + 1 < a.nframes;
+        uint32_t dm0[4], m0, m1 = 0, pc0, pm0, pc1 = 0, pm1 = 0;
         if (PAIR) st = g.p[d];
-        const uint32_t run0 = run;
-        const uint64_t m0 = pack_step2(g.c[d], st, tc, rec, run, tile, a.ntiles, c0);
-        run += (uint32_t)__builtin_popcountll(m0);
-        const uint32_t run1 = run;
-        if (PAIR) st = g.p[d + 1];
-        const uint64_t m1 = pack_step2(g.c[d + 1], st, tc, rec, run, tile, a.ntiles, c1);
-        run += (uint32_t)__builtin_popcountll(m1);
-        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane(wave_inclusive_scan((int)(c0 | (c1 << 16))), 63);
-        const uint32_t n0 = ((tot & 0xffffu) - 64u * 24u) >> 2, n1 = ((tot >> 16) - 64u * 24u) >> 2;
-        write_lane(meta.x, (uint32_t)m0, d);
-        write_lane(meta.y, (uint32_t)(m0 >> 32), d);
-        write_lane(meta.z, n0, d);
-        write_lane(meta.w, run0, d);
-        write_lane(meta.x, (uint32_t)m1, d + 1);
-        write_lane(meta.y, (uint32_t)(m1 >> 32), d + 1);
-        write_lane(meta.z, n1, d + 1);
-        write_lane(meta.w, run1, d + 1);
+        compare_step(g.c[d], st, tc, dm0, m0);
+        const uint32_t c0 = emit_step(dm0, m0, lg, lp, jump, lane24, pc0, pm0);
+        uint32_t c1 = 0;
+        if (two) {
+            if (PAIR) st = g.p[d + 1];
+            uint32_t dm1[4];
+            compare_step(g.c[d + 1], st, tc, dm1, m1);
+            c1 = emit_step(dm1, m1, lg, lp, jump, lane24, pc1, pm1);
+        }
+        // flagged bytes of the two frames: one register (16-bit fields, a tile holds at most 1024) and one
+        // DPP reduction for both
+        const uint32_t both = (uint32_t)__builtin_popcount(m0) | ((uint32_t)__builtin_popcount(m1) << 16);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane(wave_inclusive_scan((int)both), 63);
+        // all values are wave-uniform: v_writelane drops them into lanes d and d+1
+        write_lane(meta.x, pc0, d);
+        write_lane(meta.y, pm0, d);
+        write_lane(meta.z, tot & 0xffffu, d);
+        write_lane(meta.w, c0, d);
+        write_lane(meta.x, pc1, d + 1);
+        write_lane(meta.y, pm1, d + 1);
+        write_lane(meta.z, tot >> 16, d + 1);
+        write_lane(meta.w, c1, d + 1);
     }
-#if MI355_ABLATE != 2
+#if MI355_ABLATE != 2 && MI355_ABLATE != 3
     const uint32_t moff = (__umul24((uint32_t)t0 + (uint32_t)lane, a.ntiles) + tile) * 16u;
     const u32x4 mv = {meta.x, meta.y, meta.z, meta.w};
-    __builtin_amdgcn_raw_buffer_store_b128(mv, metab, lane < kPrefetch ? moff : kOOB, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(mv, lg.meta, (lane < kPrefetch && t0 + lane < a.nframes) ? moff : kOOB, 0, 0);
 #endif
 }
 
@@ -294,49 +217,30 @@ __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint
                                           int valid, int lane) {
     const int T = a.nframes;
     const ThrConst tc{(127u - (uint32_t)a.thr) * 0x01010101u, (uint32_t)a.thr * 0x01010101u};
+    const LogOut lg{make_rsrc(a.codes, a.codes_bytes), make_rsrc(a.rec, a.rec_bytes), make_rsrc(a.meta, a.meta_bytes)};
 
     uint4 st = make_uint4(0, 0, 0, 0);
     if (!PAIR) st = load16<FAST>(a.state + byte_off, valid);
-    uint32_t run = 0;  // records this tile has appended to its log so far
-    int t0 = 0;
 
-#if MI355_K1V == 2
-    if (FAST) {
-        // complete groups, two per iteration (the register groups swap roles), exact waits (see above)
-        const __amdgpu_buffer_rsrc_t rec = make_rsrc(a.rec, a.rec_bytes);
-        const __amdgpu_buffer_rsrc_t metab = make_rsrc(a.meta, a.meta_bytes);
-        Group2<PAIR> ga, gb;
-        // two groups per round; the first round is peeled so that the loop is entered with exactly the operations
-        // in flight that its back edge carries (the compiler merges the wait counts of both entries to the smaller)
-        auto round = [&]() __attribute__((always_inline)) {
-            gb.load(a, byte_off, t0 + kPrefetch);
-            pack_group2<PAIR>(a, ga, t0, st, run, tile, tc, lane, rec, metab);
-            ga.load(a, byte_off, t0 + 2 * kPrefetch);
-            pack_group2<PAIR>(a, gb, t0 + kPrefetch, st, run, tile, tc, lane, rec, metab);
-            t0 += 2 * kPrefetch;
-        };
-        if (T >= 2 * kPrefetch) {
-            ga.load(a, byte_off, 0);
-            round();
-            while (t0 + 2 * kPrefetch <= T) round();
-        }
-    }
-#endif
-    // the general form: the (up to 2 * kPrefetch - 1) frames the steady state leaves, batches shorter than
-    // that, and ragged tiles
-    if (t0 < T) {
-        Group<PAIR, FAST> ga, gb;
-        ga.load(a, byte_off, t0, valid);
-        for (;;) {
-            gb.load(a, byte_off, t0 + kPrefetch, valid);
-            pack_group<PAIR, FAST>(a, ga, t0, st, run, tile, tc, lane);
-            t0 += kPrefetch;
-            if (t0 >= T) break;
-            ga.load(a, byte_off, t0 + kPrefetch, valid);
-            pack_group<PAIR, FAST>(a, gb, t0, st, run, tile, tc, lane);
-            t0 += kPrefetch;
-            if (t0 >= T) break;
-        }
+    // Two register groups: while one is processed (its stores are issued), the other's loads are in
+    // flight.
+    Group<PAIR, FAST> ga, gb;
+    LogPos lp{tile * 1024u, 256u, tile * 1024u, 64u};   // codes / records this tile has appended to its logs so far
+    const size_t gstep = (size_t)kPrefetch * a.stride;
+    const uint8_t *cur_last = a.cur + (size_t)(T - 1) * a.stride, *prev_last = PAIR ? a.prev + (size_t)(T - 1) * a.stride : nullptr;
+    const uint8_t *cp = a.cur, *pp = a.prev;   // frame t0 + kPrefetch, the next group to request
+    ga.load(a, byte_off, 0, valid, cp, pp, cur_last, prev_last);
+    for (int t0 = 0;;) {
+        cp += gstep; if (PAIR) pp += gstep;
+        gb.load(a, byte_off, t0 + kPrefetch, valid, cp, pp, cur_last, prev_last);
+        pack_group<PAIR, FAST>(a, ga, t0, st, lp, tile, tc, lane, lg);
+        t0 += kPrefetch;
+        if (t0 >= T) break;
+        cp += gstep; if (PAIR) pp += gstep;
+        ga.load(a, byte_off, t0 + kPrefetch, valid, cp, pp, cur_last, prev_last);
+        pack_group<PAIR, FAST>(a, gb, t0, st, lp, tile, tc, lane, lg);
+        t0 += kPrefetch;
+        if (t0 >= T) break;
     }
 
     if (!PAIR) {
@@ -498,33 +402,21 @@ hipError_t launch_scan(const uint4 *meta, uint32_t *groff, uint32_t *totals, uin
     return hipGetLastError();
 }
 
-// ---- expand: records -> packed frame-major (xs, diff) -------------------------------------------------
+// ---- expand: codes + records -> packed frame-major (xs, diff) ------------------------------------------
 // grid = (ceil(W/16) rounded up to a multiple of 8, T), block = 64: one wave owns 16 consecutive tiles of
 // ONE frame, i.e. one contiguous range of that frame's output.  The wave loads the meta words of its whole
 // 64-tile group (the scan kernel gives the bytes in front of the group, the wave adds those in front of
-// its own 16 tiles) and keeps the per-tile facts in registers (readlane / ds_bpermute).  For every
-// candidate lane of its tiles it writes (tile, lane) at the record's rank into a small LDS table (ballot +
-// mbcnt), so that "record r of the wave" is found with one LDS read; 64 records are loaded per round,
-// their 16-bit maps of nonzero (= flagged) bytes come from v_dot4_u32_u8, the entry offsets from one DPP
-// scan; entries are staged in LDS in output order and leave with coalesced stores.  No barriers.
-// Measured (profiles/README.md): the kernel is bound by the log's round trip through the memory system
-// (without its record reads it takes 0.13 ms instead of 0.23 ms per 256-frame batch -- and the NEXT
-// k_diff_pack then takes 0.09 ms longer, because its record stores no longer find their lines cached);
-// instruction count, occupancy, barriers and XCD placement were each varied without effect.
-#ifndef MI355_XLIGHT
-#define MI355_XLIGHT 4
-#endif
-constexpr uint32_t kXLight = MI355_XLIGHT;   // records with more flagged bytes than this are "heavy"
-constexpr int kXHeavyMax = 12;               // more heavy records than this in a wave: everybody walks
-
+// its own 16 tiles) and keeps the per-tile facts in registers (ds_bpermute).  A small LDS table maps
+// "candidate r of the wave" to its tile; candidates are taken 64 at a time, four rounds to a pass: the codes
+// of a pass are requested together, then the records of its multi-byte lanes, then everything is staged in
+// LDS in output order (entry offsets from one DPP scan per round) and leaves with coalesced stores.
+// A code with one flagged byte IS its entry; only multi-byte lanes walk the bits of their map.  No barriers.
+//
 // WIRE: the entries leave in the sender's byte stream instead (server/src/threads.cpp:227-229): frame t
 // is {u32 n, i32 xs[n], u8 diff[n]} at byte 4t + 5*offsets[t] of a.wire, so index and payload sections
 // start at arbitrary byte addresses (gfx950 global stores need no alignment).
 __device__ __forceinline__ void store_u32_unaligned(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 
-// Entries [first, first + count) of a workgroup of NT threads, staged in LDS at s_xs/s_df[0..count), leave with coalesced
-// stores: one dword per index, and the differences as whole dwords too (byte stores only for the up to
-// three bytes before and after the dword-aligned body of the destination).
 // Hand-off between lanes of ONE wave through LDS (k_expand is a single-wave workgroup): the DS operations of a
 // wave execute in order, so this costs nothing in hardware; it keeps the compiler from moving LDS accesses
 // across the hand-off.
@@ -533,10 +425,13 @@ __device__ __forceinline__ void lds_handoff() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <bool WIRE, uint32_t NT>
-__device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint16_t *s_xs, const uint8_t *s_df,
-                                              uint32_t first, uint32_t count, uint32_t xs0, uint32_t dst0,
-                                              uint8_t *w_xs, uint8_t *w_df, size_t w_room) {
+// Entries [first, first + count) of the wave, staged in LDS as (index relative to xs0) << 8 | difference, leave with
+// coalesced stores: one dword per index, and the differences as whole dwords too (byte stores only for the up to
+// three bytes before and after the dword-aligned body of the destination).
+template <bool WIRE>
+__device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint32_t *stage, uint32_t first, uint32_t count,
+                                              uint32_t xs0, uint32_t dst0, uint8_t *w_xs, uint8_t *w_df, size_t w_room) {
+    const uint32_t lane = threadIdx.x;
     uint8_t *xsp, *dfp;
     uint32_t n;
     if (WIRE) {
@@ -549,140 +444,239 @@ __device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint16_
         xsp = (uint8_t *)(a.out_xs + d);
         dfp = a.out_diff + d;
     }
-    for (uint32_t i = threadIdx.x; i < n; i += NT) store_u32_unaligned(xsp + 4 * (size_t)i, xs0 + s_xs[i]);
+#if MI355_XABLATE == 4
+    if (xs0 != 0xfffffff0u) n = 0;
+#endif
+    for (uint32_t i = lane; i < n; i += 64u) store_u32_unaligned(xsp + 4 * (size_t)i, xs0 + (stage[i] >> 8));
     const uint32_t lead = (4u - (uint32_t)((uintptr_t)dfp & 3u)) & 3u;
     const uint32_t head = lead < n ? lead : n;
     const uint32_t body = (n - head) >> 2;
-    if (threadIdx.x < head) dfp[threadIdx.x] = s_df[threadIdx.x];
-    for (uint32_t k = threadIdx.x; k < body; k += NT) {
-        const uint8_t *q = s_df + head + 4 * k;
-        const uint32_t v = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
-        *reinterpret_cast<uint32_t *>(dfp + head + 4 * (size_t)k) = v;
+    if (lane < head) dfp[lane] = (uint8_t)stage[lane];
+    for (uint32_t k = lane; k < body; k += 64u) {
+        const uint32_t *q = stage + head + 4 * k;
+        // the low bytes of four entries: v_perm picks byte 0 of two dwords at a time
+        const uint32_t lo = __builtin_amdgcn_perm(q[1], q[0], 0x0c0c0400u), hi = __builtin_amdgcn_perm(q[3], q[2], 0x04000c0cu);
+        *reinterpret_cast<uint32_t *>(dfp + head + 4 * (size_t)k) = lo | hi;
     }
-    const uint32_t tail = head + 4 * body + threadIdx.x;
-    if (tail < n) dfp[tail] = s_df[tail];
+    const uint32_t tail = head + 4 * body + lane;
+    if (tail < n) dfp[tail] = (uint8_t)stage[tail];
 }
 
-constexpr uint32_t kWTiles = 16;       // tiles per single-wave workgroup
-constexpr uint32_t kWStage = 1024;     // entries staged per wave = the most a round of 64 records can hold (5 KB of LDS per wave in all)
+#ifndef MI355_XTILES
+#define MI355_XTILES 16
+#endif
+#ifndef MI355_XROUNDS
+#define MI355_XROUNDS 3
+#endif
+// Ablation builds of the expander (tools/ab_build.sh, never shipped): 1 = prologue only (meta, scans), 2 = + table and
+// code loads, 3 = + record loads, 4 = + staging in LDS but no output stores.  0 = the product.
+#ifndef MI355_XABLATE
+#define MI355_XABLATE 0
+#endif
+constexpr uint32_t kWTiles = MI355_XTILES;   // tiles per single-wave workgroup (16, 32 or 64: a divisor of kXTiles)
+constexpr uint32_t kWPerGroup = 64u / kWTiles;
+constexpr uint32_t kWStage = 1024;     // entries staged per wave = the most a round of 64 candidates can hold
+constexpr int kXRounds = MI355_XROUNDS;      // rounds of 64 candidates whose loads are requested together
+#ifndef MI355_XLIGHT
+#define MI355_XLIGHT 4
+#endif
+constexpr uint32_t kXLight = MI355_XLIGHT;   // lanes with more flagged bytes than this are expanded by 16 lanes
+
+// What a wave needs before it can start on its item (frame t, tiles 16 sub .. 16 sub + 15).
+struct ItemPro {
+    uint4 m;          // lane L: meta word of tile L of the item's 64-tile group
+    uint32_t off_t;   // entries of the frames before t
+    uint32_t goff;    // entries of frame t before the group
+    uint32_t n_t;     // WIRE: entries of frame t
+};
 
 template <bool WIRE>
-__global__ __launch_bounds__(64) void k_expand(const ExpandArgs a) {
-    __shared__ uint16_t s_src[kWTiles * 64];
-    __shared__ uint16_t s_xs[kWStage];
-    __shared__ uint8_t s_df[kWStage];
-    const int lane = threadIdx.x;
-    const int t = blockIdx.y;
-    const uint32_t sub = blockIdx.x, group = sub >> 2, q = sub & 3u;
-    const uint32_t tile0 = sub * kWTiles, gtile0 = group * kXTiles;
+__device__ __forceinline__ ItemPro load_item(const ExpandArgs &a, uint32_t t, uint32_t sub, uint32_t ngroups, uint32_t lane) {
+    ItemPro p;
+    const uint32_t group = sub / kWPerGroup, gtile = group * kXTiles + lane;
+    p.m = make_uint4(0, 0, 0, 0);
+    if (gtile < a.ntiles) p.m = a.meta[(size_t)t * a.ntiles + gtile];
+    p.off_t = a.offsets[t];
+    p.goff = a.groff[(size_t)t * ngroups + group];
+    p.n_t = WIRE ? a.offsets[t + 1] - p.off_t : 0u;
+    return p;
+}
+
+// grid = (ceil(W/16), T) single-wave workgroups: one item each (the hardware's dispatcher balances the items;
+// a persistent grid walking them with a fixed stride was measured 0.05 ms slower per batch: the slowest wave's
+// share decides, and the waves fall into step).  8 waves per SIMD (the register budget is set for that): the
+// kernel is a chain of short dependent steps, what hides them is the number of waves.
+template <bool WIRE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_expand(const ExpandArgs a) {
+    __shared__ uint8_t s_tile[kWTiles * 64];      // candidate of the wave -> its tile
+    __shared__ uint2 s_tinfo[kWTiles];            // per tile: {byte offset of its candidate 0 in the code log - 4 * (candidates before the tile), byte offset of its first record}
+    __shared__ uint32_t s_stage[kWStage];         // (byte index relative to the wave's first tile) << 8 | difference
+    const uint32_t lane = threadIdx.x;
     const uint32_t ngroups = (a.ntiles + kXTiles - 1) / kXTiles;
-    if (tile0 >= a.ntiles) return;   // grid.x is padded to a multiple of 8 (see launch_expand)
-    const size_t row = (size_t)t * a.ntiles;
-    const uint32_t off_t = a.offsets[t];
-    const uint32_t goff = a.groff[(size_t)t * ngroups + group];
-    uint32_t n_t = 0;
-    size_t head = 0;
-    if (WIRE) {
-        n_t = a.offsets[t + 1] - off_t;
-        head = 4 * (size_t)t + 5 * (size_t)off_t;
-        if (sub == 0 && lane == 0 && head + 4 <= a.capacity) store_u32_unaligned(a.wire + head, n_t);
-    }
-    // lane L <-> tile gtile0 + L of the group; lanes 16q .. 16q+15 are this wave's tiles
-    uint4 m = make_uint4(0, 0, 0, 0);
-    if (gtile0 + (uint32_t)lane < a.ntiles) m = a.meta[row + gtile0 + (uint32_t)lane];
-    const uint64_t mask = (uint64_t)m.x | ((uint64_t)m.y << 32);
-    const bool mine = ((uint32_t)lane >> 4) == q;
-    const uint32_t nr = mine ? (uint32_t)__builtin_popcountll(mask) : 0u;
-    const uint32_t rincl = (uint32_t)wave_inclusive_scan((int)nr);
-    const uint32_t bincl = (uint32_t)wave_inclusive_scan((int)m.z);
-    const uint32_t nrec = (uint32_t)__builtin_amdgcn_readlane((int)rincl, 63);
-    if (nrec == 0) return;
-    const uint32_t before = q ? (uint32_t)__builtin_amdgcn_readlane((int)bincl, (int)(16u * q - 1u)) : 0u;
-    const uint32_t dst0 = off_t + goff + before;   // < 2^32: the batch total is below 2^32
-    const uint32_t rexcl = rincl - nr;             // records of this wave before the lane's tile
-    const uint32_t rbase = m.w - rexcl;            // + record index in the wave = log position of the record
-    uint8_t *w_xs = nullptr, *w_df = nullptr;
-    size_t w_room = 0;
-    if (WIRE) {
-        const size_t end = head + 4 + 5 * (size_t)n_t;
-        const uint32_t seg = dst0 - off_t;
-        w_xs = a.wire + head + 4 + 4 * (size_t)seg;
-        w_df = a.wire + head + 4 + 4 * (size_t)n_t + seg;
-        w_room = end <= a.capacity ? (size_t)n_t : 0;
-    }
-    // where each record of the wave comes from: candidate lanes write (tile, lane) at the record's rank
+    const uint32_t t = blockIdx.y, sub = blockIdx.x;
+    if (sub * kWTiles >= a.ntiles) return;   // grid.x is padded to a multiple of 8 (see launch_expand)
+    const ItemPro cur = load_item<WIRE>(a, t, sub, ngroups, lane);
+    {
+        const uint32_t q = sub % kWPerGroup, tile0 = sub * kWTiles;
+        const uint4 m = cur.m;   // {code offset, record offset, flagged bytes, candidates | multi << 16}
+        size_t head = 0;
+        if (WIRE) {
+            head = 4 * (size_t)t + 5 * (size_t)cur.off_t;
+            if (sub == 0 && lane == 0 && head + 4 <= a.capacity) store_u32_unaligned(a.wire + head, cur.n_t);
+        }
+        // lane L <-> tile L of the group; lanes kWTiles * q .. kWTiles * (q + 1) - 1 are this wave's tiles
+        const bool mine = lane / kWTiles == q;
+        const uint32_t nc = mine ? (m.w & 0xffffu) : 0u;
+        const uint32_t rincl = (uint32_t)wave_inclusive_scan((int)nc);
+        const uint32_t bincl = (uint32_t)wave_inclusive_scan((int)m.z);
+        const uint32_t nrec = (uint32_t)__builtin_amdgcn_readlane((int)rincl, 63);
+        if (nrec != 0) {
+            const uint32_t before = q ? (uint32_t)__builtin_amdgcn_readlane((int)bincl, (int)(kWTiles * q - 1u)) : 0u;
+            const uint32_t dst0 = cur.off_t + cur.goff + before;   // < 2^32: the batch total is below 2^32
+            const uint32_t rexcl = rincl - nc;                     // candidates of this wave before the lane's tile
+            uint8_t *w_xs = nullptr, *w_df = nullptr;
+            size_t w_room = 0;
+            if (WIRE) {
+                const size_t end = head + 4 + 5 * (size_t)cur.n_t;
+                const uint32_t seg = dst0 - cur.off_t;
+                w_xs = a.wire + head + 4 + 4 * (size_t)seg;
+                w_df = a.wire + head + 4 + 4 * (size_t)cur.n_t + seg;
+                w_room = end <= a.capacity ? (size_t)cur.n_t : 0;
+            }
+#if MI355_XABLATE == 1
+            if (dst0 == 0xfffffff0u) a.out_xs[0] = (int32_t)nrec;
+#else
+            if (mine) s_tinfo[lane % kWTiles] = make_uint2(m.x - 4u * rexcl, m.y);
+            // which tile candidate r of the wave belongs to: tile i owns ranks rexcl_i .. rexcl_i + nc_i - 1
 #pragma unroll 4
-    for (uint32_t i = 0; i < kWTiles; i++) {
-        const int L = (int)(16u * q + i);
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mask, L);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mask >> 32), L);
-        const uint32_t rx = (uint32_t)__builtin_amdgcn_readlane((int)rexcl, L);
-        const uint64_t mk = (uint64_t)lo | ((uint64_t)hi << 32);
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-        if ((mk >> lane) & 1) s_src[rx + rank] = (uint16_t)((i << 6) | (uint32_t)lane);
-    }
-    lds_handoff();   // s_src is read by other lanes than the ones that wrote it
-    const uint32_t xs_base = tile0 * kTileBytes;
-    uint32_t carry = 0, flushed = 0;   // entries emitted / already stored
-    for (uint32_t base = 0; base < nrec; base += 64) {
-        const uint32_t r = base + (uint32_t)lane;
-        const uint32_t src = r < nrec ? s_src[r] : 0u;
-        const uint32_t sgm = src >> 6;
-        // every lane takes part in the permute; the value comes from the lane that holds tile sgm of this wave
-        const uint32_t rb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u * q + sgm) * 4u), (int)rbase);
-        const uint32_t src16 = src * 16u;
-        uint4 rec = make_uint4(0, 0, 0, 0);
-        if (r < nrec) rec = a.rec[rec_index(r + rb, tile0 + sgm, a.ntiles)];
-        const uint32_t m16 = record_map16(rec);
-        const uint32_t cnt = (uint32_t)__builtin_popcount(m16);
-        const uint32_t incl = (uint32_t)wave_inclusive_scan((int)cnt);
-        const uint32_t round_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (carry - flushed + round_total > kWStage) {   // wave-uniform: make room
-            lds_handoff();
-            flush_entries<WIRE, 64>(a, s_xs, s_df, flushed, carry - flushed, xs_base, dst0, w_xs, w_df, w_room);
-            lds_handoff();   // the stage is rewritten from its start
-            flushed = carry;
-        }
-        uint32_t e = carry - flushed + incl - cnt;        // index in the LDS stage
-        carry += round_total;
-        uint32_t mm = m16;
-        const uint64_t heavy = __ballot(cnt > kXLight);
-        const bool coop = __builtin_popcountll(heavy) <= kXHeavyMax;
-        const uint32_t e0 = e;
-        if (coop && cnt > kXLight) mm = 0;
-        while (mm) {
-            const int b = __builtin_ctz(mm);
-            mm &= mm - 1;
-            const uint32_t dw = b < 8 ? (b < 4 ? rec.x : rec.y) : (b < 12 ? rec.z : rec.w);
-            s_xs[e] = (uint16_t)(src16 + (uint32_t)b);                       // kernels.cu:315
-            s_df[e] = (uint8_t)(dw >> (8 * (b & 3)));                        // kernels.cu:314
-            ++e;
-        }
-        if (coop) {
-            const uint32_t b = (uint32_t)lane & 15u;
-            for (uint64_t h = heavy; h; h &= h - 1) {
-                const int hl = __builtin_ctzll(h);
-                const uint32_t r0 = __builtin_amdgcn_readlane(rec.x, hl);
-                const uint32_t r1 = __builtin_amdgcn_readlane(rec.y, hl);
-                const uint32_t r2 = __builtin_amdgcn_readlane(rec.z, hl);
-                const uint32_t r3 = __builtin_amdgcn_readlane(rec.w, hl);
-                const uint32_t hm = __builtin_amdgcn_readlane(m16, hl);
-                const uint32_t ee = __builtin_amdgcn_readlane(e0, hl);
-                const uint32_t sb = __builtin_amdgcn_readlane(src16, hl);
-                if (lane < 16 && ((hm >> b) & 1u)) {
-                    const uint32_t pos = ee + (uint32_t)__builtin_popcount(hm & ((1u << b) - 1u));
-                    const uint32_t dw = b < 8 ? (b < 4 ? r0 : r1) : (b < 12 ? r2 : r3);
-                    s_xs[pos] = (uint16_t)(sb + b);
-                    s_df[pos] = (uint8_t)(dw >> (8 * (b & 3)));
+            for (uint32_t i = 0; i < kWTiles; i++) {
+                const int L = (int)(kWTiles * q + i);
+                const uint32_t nci = (uint32_t)__builtin_amdgcn_readlane((int)nc, L);
+                const uint32_t rx = (uint32_t)__builtin_amdgcn_readlane((int)rexcl, L);
+                if (lane < nci) s_tile[rx + lane] = (uint8_t)i;
+            }
+            lds_handoff();   // the tables are read by other lanes than the ones that wrote them
+            const uint32_t xs_base = tile0 * kTileBytes;
+            uint32_t carry = 0, flushed = 0;   // entries emitted / already stored
+            for (uint32_t base = 0; base < nrec; base += 64u * kXRounds) {
+                // (1) the codes of the pass: table reads, then loads, back to back (indices clamped, not masked)
+                uint32_t code[kXRounds], src16[kXRounds], pm[kXRounds];
+                {
+                    uint32_t rr[kXRounds], ti[kXRounds];
+                    uint2 inf[kXRounds];
+#pragma unroll
+                    for (int k = 0; k < kXRounds; k++) {
+                        rr[k] = min(base + 64u * (uint32_t)k + lane, nrec - 1u);
+                        ti[k] = s_tile[rr[k]];
+                    }
+#pragma unroll
+                    for (int k = 0; k < kXRounds; k++) inf[k] = s_tinfo[ti[k]];
+#pragma unroll
+                    for (int k = 0; k < kXRounds; k++) {
+                        code[k] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(a.codes) + (inf[k].x + 4u * rr[k]));
+                        pm[k] = inf[k].y;
+                        src16[k] = ti[k] * kTileBytes;
+                    }
+#pragma unroll
+                    for (int k = 0; k < kXRounds; k++) {
+                        if (base + 64u * (uint32_t)k + lane >= nrec) code[k] = 0;   // also whole rounds beyond the wave's candidates
+                        src16[k] += ((code[k] >> 24) & 63u) * 16u;                  // first byte of the lane, relative to the wave's first tile
+                    }
+                }
+#if MI355_XABLATE == 2
+                { uint32_t acc = 0;
+#pragma unroll
+                  for (int k = 0; k < kXRounds; k++) acc ^= code[k];
+                  if (acc == 0xfffffff0u) a.out_xs[0] = (int32_t)acc; }
+                continue;
+#endif
+                // (2) the records of its multi-byte lanes
+                uint4 rec[kXRounds];
+#pragma unroll
+                for (int k = 0; k < kXRounds; k++) {
+                    const uint32_t m16 = code[k] & 0xffffu;
+                    rec[k] = make_uint4(0, 0, 0, 0);
+                    if (m16 & (m16 - 1u))
+                        rec[k] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(a.rec) + (pm[k] + ((code[k] >> 16) & 0xffu) * 16u));
+                }
+#if MI355_XABLATE == 3
+                { uint32_t acc = 0;
+#pragma unroll
+                  for (int k = 0; k < kXRounds; k++) acc ^= code[k] ^ rec[k].x ^ rec[k].y ^ rec[k].z ^ rec[k].w;
+                  if (acc == 0xfffffff0u) a.out_xs[0] = (int32_t)acc; }
+                continue;
+#endif
+                // (3) stage the entries in output order
+#pragma unroll
+                for (int k = 0; k < kXRounds; k++) {
+                    if (base + 64u * (uint32_t)k >= nrec) break;   // wave-uniform
+                    const uint32_t m16 = code[k] & 0xffffu;
+                    const uint32_t cnt = (uint32_t)__builtin_popcount(m16);
+                    const uint32_t incl = (uint32_t)wave_inclusive_scan((int)cnt);
+                    const uint32_t round_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    if (carry - flushed + round_total > kWStage) {   // wave-uniform: make room
+                        lds_handoff();
+                        flush_entries<WIRE>(a, s_stage, flushed, carry - flushed, xs_base, dst0, w_xs, w_df, w_room);
+                        lds_handoff();   // the stage is rewritten from its start
+                        flushed = carry;
+                    }
+                    const uint32_t e = carry - flushed + incl - cnt;        // index in the LDS stage
+                    carry += round_total;
+                    // lanes with more than kXLight flagged bytes (object edges among isolated bytes) would make the whole
+                    // wave walk their bits: they are expanded by 16 lanes each afterwards, four at a time
+                    const uint64_t heavy = __ballot(cnt > kXLight);
+                    if (cnt == 1u) {
+                        s_stage[e] = ((src16[k] + (uint32_t)__builtin_ctz(m16)) << 8) | ((code[k] >> 16) & 0xffu);   // kernels.cu:314-315
+                    } else if (cnt > 1u && cnt <= kXLight) {
+                        uint32_t mm = m16, ee = e;
+                        do {
+                            const int b = __builtin_ctz(mm);
+                            mm &= mm - 1;
+                            const uint32_t dw = b < 8 ? (b < 4 ? rec[k].x : rec[k].y) : (b < 12 ? rec[k].z : rec[k].w);
+                            s_stage[ee] = ((src16[k] + (uint32_t)b) << 8) | ((dw >> (8 * (b & 3))) & 0xffu);
+                            ++ee;
+                        } while (mm);
+                    }
+                    if (heavy) {   // wave-uniform
+                        const uint32_t g = lane >> 4, b = lane & 15u;
+                        uint64_t h = heavy;
+                        do {
+                            // the lanes of (up to) four heavy records; a missing one repeats the first and is masked out
+                            const int l0 = __builtin_ctzll(h);
+                            h &= h - 1;
+                            const int l1 = h ? __builtin_ctzll(h) : -1;
+                            h = h ? h & (h - 1) : 0;
+                            const int l2 = h ? __builtin_ctzll(h) : -1;
+                            h = h ? h & (h - 1) : 0;
+                            const int l3 = h ? __builtin_ctzll(h) : -1;
+                            h = h ? h & (h - 1) : 0;
+                            const int srcl = g == 0 ? l0 : (g == 1 ? l1 : (g == 2 ? l2 : l3));
+                            const int sa = (srcl < 0 ? l0 : srcl) * 4;
+                            const uint32_t r0 = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)rec[k].x);
+                            const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)rec[k].y);
+                            const uint32_t r2 = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)rec[k].z);
+                            const uint32_t r3 = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)rec[k].w);
+                            const uint32_t hm = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)m16);
+                            const uint32_t he = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)e);
+                            const uint32_t hs = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)src16[k]);
+                            if (srcl >= 0 && ((hm >> b) & 1u)) {
+                                const uint32_t pos = he + (uint32_t)__builtin_popcount(hm & ((1u << b) - 1u));
+                                const uint32_t dw = b < 8 ? (b < 4 ? r0 : r1) : (b < 12 ? r2 : r3);
+                                s_stage[pos] = ((hs + b) << 8) | ((dw >> (8 * (b & 3))) & 0xffu);
+                            }
+                        } while (h);
+                    }
                 }
             }
+            lds_handoff();
+            flush_entries<WIRE>(a, s_stage, flushed, carry - flushed, xs_base, dst0, w_xs, w_df, w_room);
+#endif
         }
     }
-    lds_handoff();
-    flush_entries<WIRE, 64>(a, s_xs, s_df, flushed, carry - flushed, xs_base, dst0, w_xs, w_df, w_room);
 }
 
 hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s) {
+    static_assert(64u % kWTiles == 0 && kWTiles >= 16, "a wave owns a whole fraction of a 64-tile group");
     // Workgroups go to the 8 XCDs round-robin by linear id: with grid.x a multiple of 8 the workgroups of one
     // tile range land on the same XCD for every frame (the padding workgroups return at once).
     const uint32_t gx = (a.ntiles + kWTiles - 1) / kWTiles;

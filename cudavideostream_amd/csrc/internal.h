@@ -22,13 +22,16 @@ struct PackArgs {
     int32_t nframes;       // T
     int32_t thr;           // threshold
     uint32_t ntiles;       // W = ceil(n / 1024)
-    uint4 *rec;            // record log: T chunks x W tiles x 64 records of 16 masked diff bytes
-    uint4 *meta;           // [T][W]: {candidate ballot lo, hi, flagged bytes, log position}
-    uint32_t rec_bytes;    // sizes of the two logs (buffer descriptors of the steady-state loop; both < 2^32)
+    uint32_t *codes;       // code log: T/4 chunks x W tiles x 256 codes (one per candidate lane)
+    uint4 *rec;            // record log: T chunks x W tiles x 64 records of 16 masked diff bytes (multi-byte lanes)
+    uint4 *meta;           // [T][W]: {code position, record position, flagged bytes, candidates | multi-byte lanes << 16}
+    uint32_t codes_bytes;  // sizes of the logs (buffer descriptors; all < 2^32)
+    uint32_t rec_bytes;
     uint32_t meta_bytes;
 };
 
 struct ExpandArgs {
+    const uint32_t *codes;
     const uint4 *rec;
     const uint4 *meta;        // [T][W]
     const uint32_t *groff;    // [T][G]  flagged bytes of the frame before each group of 64 tiles (G = ceil(W/64))

@@ -26,7 +26,8 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
 // v_writelane_b32: put a wave-uniform value into one lane of a VGPR (1 instruction instead of
 // v_mov + v_cndmask); `lane` must be a compile-time constant here.
 __device__ __forceinline__ void write_lane(uint32_t &v, uint32_t uniform_value, int lane) {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(uniform_value), "n"(lane));
+    // (readfirstlane: free when the value already lives in an SGPR; the compiler keeps some uniform values in VGPRs)
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane((int)uniform_value)), "n"(lane));
 }
 
 // ---- per-dword byte arithmetic (4 bytes per instruction) --------------------------------------------
