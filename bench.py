@@ -12,6 +12,14 @@ N GPUs : one process per GPU (torch.distributed, backend nccl = RCCL); every ran
          gather of the per-frame index to rank 0 every step plus ONE gather-v of the final batch's
          changed-pixel payload inside the timed region (--gather every|last|index|none).
 
+         `python bench.py --gpus N` starts the N ranks itself when no launcher has (WORLD_SIZE unset); under
+         `python -m torch.distributed.run ... bench.py --gpus N` this process is one of them.  With N > 1 the line also
+         carries ranks_seen, gather_ms / gather_bytes (the exchange inside the timed region) and `gather_every` (the same
+         job with a gather after EVERY batch).  If the RCCL group below the C-ABI cannot be formed the run FAILS
+         (exit 3) unless --allow-gather-fallback is given.
+config 5 (BASELINE.json configs[4], 4K frames dealt round-robin over the GPUs, RCCL gather over xGMI):
+         python bench.py --gpus 8 --shard roundrobin --width 3840 --height 2160 --batch 64
+
 Prints ONE JSON line on rank 0.  The CPU oracle is used only as the checker / cpu_baseline leg.
 """
 import argparse
@@ -116,6 +124,11 @@ def parse():
     p.add_argument("--no-pair", action="store_true")
     p.add_argument("--no-host-path", action="store_true")
     p.add_argument("--no-filters", action="store_true", help="skip the config3 / config4 objects")
+    p.add_argument("--allow-gather-fallback", action="store_true",
+                   help="N > 1 only: if the RCCL group below the C-ABI cannot be formed, measure the torch.distributed "
+                        "form of the exchange instead of failing (the line then says so in config.gather_impl)")
+    p.add_argument("--gather-every-steps", type=int, default=10,
+                   help="N > 1: steps of the secondary `gather_every` measurement (a gather after EVERY batch)")
     return p.parse_args()
 
 
@@ -215,8 +228,26 @@ def reference_filter_chain(args, h_base, h_frames, nframes=8):
                       f"{len(ms)} readings of its own FOR: counter"}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (torch.distributed.run, one process
+    per GPU, rendezvous on 127.0.0.1), BEFORE anything in this process touches the GPU, hand their one JSON line through
+    and leave with their exit code.  (With WORLD_SIZE set -- the driver's `python -m torch.distributed.run ... bench.py`
+    -- this process IS a rank and nothing is spawned.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     # stdout carries exactly ONE line (the JSON record): anything libraries print while the job runs
     # (RCCL prints a version banner on stdout at communicator creation) is routed to stderr.
     sys.stdout.flush()
@@ -280,12 +311,32 @@ def main():
             group.close()
             group = None
             gather_impl = "torch.distributed (mi355_group unavailable on another rank)"
+        if group is None and not args.allow_gather_fallback:
+            # a scaling line must measure the path's own exchange: no silent change of what is timed
+            print(f"bench.py: rank {rank}: the RCCL group could not be formed ({gather_impl}); "
+                  f"--allow-gather-fallback measures the torch.distributed form instead", file=sys.stderr)
+            dist.barrier()
+            dist.destroy_process_group()
+            raise SystemExit(3)
+
+    gstat = {"ms": 0.0, "calls": 0, "bytes": 0, "ranks_seen": world if world > 1 else 1}
 
     def exchange_payload():
+        # timed on its own (a host synchronisation either side: the call has one inside anyway, kernels.cu:507-508)
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
         if group is not None:
-            group.gather(0, B, [d_off], [d_xs], [d_df], r_off, r_xs, r_df, world * cap if rank == 0 else 0)
+            counts = group.gather(0, B, [d_off], [d_xs], [d_df], cap, r_off, r_xs, r_df, world * cap if rank == 0 else 0)
+            gstat["ranks_seen"] = group.nranks
+            total = int(counts.sum())
         else:
             gx.gather_payload(d_off, d_xs, d_df, dst=0)
+            total = -1
+        torch.cuda.synchronize()
+        gstat["ms"] += (time.perf_counter() - tg) * 1e3
+        gstat["calls"] += 1
+        if total >= 0:   # what arrives at the root: every rank's index row + 5 bytes per entry, its own part included
+            gstat["bytes"] += 4 * (B + 1) * world + 5 * total
 
     def step(last):
         if rr:
@@ -306,6 +357,7 @@ def main():
     torch.cuda.synchronize()
     core.set_timing(True)
     core.reset_timing()
+    gstat.update(ms=0.0, calls=0, bytes=0)
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -324,6 +376,33 @@ def main():
 
     ms_pack, ms_scan, ms_expand, launches = core.get_kernel_timing()
     core.set_timing(False)
+    g_last = dict(gstat)
+    # secondary measurement (N > 1): the same job with the gather after EVERY batch -- the exchange at its worst
+    # (every byte of every rank funnelled to one GPU), so that the scaling curve shows what the gather costs
+    g_every = None
+    if world > 1 and args.gather != "none" and args.gather_every_steps > 0:
+        gstat.update(ms=0.0, calls=0, bytes=0)
+        K2 = args.gather_every_steps
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(K2):
+            if rr:
+                core.diff_pairs_batch(frames, prevs, B, d_off, d_xs, d_df, cap)
+            else:
+                core.diff_stream_batch(frames, B, d_off, d_xs, d_df, cap)
+            exchange_payload()
+        torch.cuda.synchronize()
+        dist.barrier()
+        e2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(e2, op=dist.ReduceOp.MAX)
+        e2 = float(e2.item())
+        g_every = {"value": round(world * B * K2 / e2, 1), "unit": "frames/s", "steps": K2,
+                   "ms_per_step": round(e2 / K2 * 1e3, 4), "gather_ms": round(gstat["ms"] / max(gstat["calls"], 1), 4),
+                   "gather_bytes": gstat["bytes"] // max(gstat["calls"], 1),
+                   "gather_gbps": round(gstat["bytes"] / max(gstat["ms"], 1e-9) / 1e6, 1),
+                   "note": "every batch's changed-pixel stream of every rank gathered to rank 0 (rank 0's own timing of "
+                           "mi355_group_gather, host synchronised either side)"}
     off = d_off.cpu().numpy().view(np.uint32)
     p_total = int(off[-1])
     assert p_total <= cap, "output capacity too small for this stream"
@@ -353,6 +432,10 @@ def main():
                        "parallelism": (f"frames round-robin over {world} ranks" if rr else
                                        f"{world} independent streams" if world > 1 else "1 stream"),
                        "gather": args.gather if world > 1 else "n/a", "gather_impl": gather_impl},
+            "ranks_seen": g_last["ranks_seen"],
+            "gather_ms": round(g_last["ms"] / g_last["calls"], 4) if g_last["calls"] else None,
+            "gather_bytes": g_last["bytes"] // g_last["calls"] if g_last["calls"] else None,
+            "gather_every": g_every,
             "roofline": path_roofline(alg_bytes, (ms_pack, ms_scan, ms_expand), launches, rr, pmc),
         }
         if world == 1 and not args.no_pair and not rr:

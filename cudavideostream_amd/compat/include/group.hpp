@@ -54,12 +54,13 @@ public:
     // the final changed-pixel gather to device `root`; returns every device's count
     std::vector<uint64_t> gather(int root, int nframes, const std::vector<void *> &d_offsets,
                                  const std::vector<void *> &d_xs, const std::vector<void *> &d_diff,
-                                 void *d_root_offsets, void *d_root_xs, void *d_root_diff, size_t root_capacity) {
+                                 size_t member_capacity, void *d_root_offsets, void *d_root_xs, void *d_root_diff,
+                                 size_t root_capacity) {
         std::vector<uint64_t> counts((size_t)size());
         std::vector<const void *> o(d_offsets.begin(), d_offsets.end()), x(d_xs.begin(), d_xs.end()),
             d(d_diff.begin(), d_diff.end());
-        check(mi355_group_gather(g_, root, nframes, o.data(), x.data(), d.data(), d_root_offsets, d_root_xs,
-                                 d_root_diff, root_capacity, counts.data()), "mi355_group_gather");
+        check(mi355_group_gather(g_, root, nframes, o.data(), x.data(), d.data(), member_capacity, d_root_offsets,
+                                 d_root_xs, d_root_diff, root_capacity, counts.data()), "mi355_group_gather");
         return counts;
     }
     void synchronize() { check(mi355_group_synchronize(g_), "mi355_group_synchronize"); }

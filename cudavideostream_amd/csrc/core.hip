@@ -9,7 +9,7 @@
 //                          of every frame), chunk-interleaved over tiles
 //   rec       T*W*64*16    record log: 16 masked diff bytes per lane with two or more flagged bytes
 //   meta      T*W*16       per (frame, tile): code position, record position, flagged bytes, candidates | multi << 16
-//   groff     T*ceil(W/64)*4;  totals (T+1)*4 (+ticket);  offsets (T+1)*4
+//   groff     T*ceil(W/64)*16 (a prefix per range of 16 tiles);  totals (T+1)*4 (+ticket);  offsets (T+1)*4
 //   one_xs N*4, one_diff N exec(): packed output of a single frame before the D2H copies
 //   hist T*256*4, thr T*4 (per frame of a filter batch), k9 9*4, heat LUT 766*3, glyph atlas
 #include <cmath>
@@ -381,7 +381,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     g.rec = c->rec;
     g.codes = c->codes;
     g.meta = c->meta;
-    g.groff = c->groff;
+    g.roff = c->groff;
     g.offsets = (const uint32_t *)d_offsets;
     g.ntiles = c->ntiles;
     g.out_xs = (int32_t *)d_xs;
@@ -442,7 +442,7 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (!rc) rc = dev_alloc(c, &c->rec, T * W * 64);
     if (!rc) rc = dev_alloc(c, &c->codes, code_chunks(T) * W * 256);
     if (!rc) rc = dev_alloc(c, &c->meta, T * W);
-    if (!rc) rc = dev_alloc(c, &c->groff, T * expand_groups(c->ntiles));
+    if (!rc) rc = dev_alloc(c, &c->groff, T * expand_groups(c->ntiles) * 4);   // one prefix per range of 16 tiles
     if (!rc) rc = dev_alloc(c, &c->totals, T + 1);   // + the scan kernel's ticket counter
     if (!rc) { e = hipMemset(c->totals, 0, (T + 1) * sizeof(uint32_t)); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipMemset", e); }
     if (!rc) rc = dev_alloc(c, &c->offsets, T + 1);

@@ -22,7 +22,7 @@
 //                 it appends a 4-byte code {map, the byte's difference, lane} to the tile's code log; a lane
 //                 with two or more flagged bytes also appends its 16 masked difference bytes to the record
 //                 log (see "the log" below).  Per (frame, tile) one 16-byte meta word.
-//   k_scan_groups: per frame, flagged bytes before every group of 64 tiles; its last workgroup scans the
+//   k_scan_groups: per frame, flagged bytes before every range of 16 tiles; its last workgroup scans the
 //               frame totals into offsets[0..T].
 //   k_expand    : one wave per (frame, 16 tiles): turns codes and records into the caller's packed,
 //                 frame-major, ascending (xs, diff) arrays -- or the socket's byte stream -- through an
@@ -121,6 +121,9 @@ __device__ __forceinline__ uint32_t emit_step(const uint32_t (&dm)[4], uint32_t 
     const uint32_t rankC = __builtin_amdgcn_mbcnt_hi((uint32_t)(bc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bc, 0u));
     const uint32_t rankM = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
     const uint32_t nc = (uint32_t)__builtin_popcountll(bc), nm = (uint32_t)__builtin_popcountll(bm);
+    pc = lp.ptrC;
+    pm = lp.ptrM;
+    if (nc == 0u) return 0u;   // wave-uniform: a still tile appends nothing (and issues no store)
     if (nc > lp.roomC) { lp.ptrC += lp.roomC * 4u + jump; lp.roomC = 256u; }
     if (nm > lp.roomM) { lp.ptrM += lp.roomM * 16u + jump; lp.roomM = 64u; }
     pc = lp.ptrC;
@@ -304,8 +307,8 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *l
     return r;
 }
 
-// A *group* is kXTiles consecutive tiles (four k_expand waves); the expander needs, per frame,
-// the bytes in the groups before its own and rebuilds everything finer from the meta words.
+// A *group* is kXTiles = 64 consecutive tiles (one wave of k_scan_groups reduces it); the expander's unit is a
+// *range* of kWTiles = 16 tiles, and it needs, per frame, the flagged bytes in the ranges before its own.
 constexpr uint32_t kXTiles = 64;          // = one wave of k_scan_groups per group
 constexpr uint32_t kScanChunk = 1024;     // groups scanned per pass of k_scan_groups
 
@@ -322,20 +325,22 @@ __device__ __forceinline__ uint32_t publish_then_take_ticket(uint32_t *slot, uin
     return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// grid = T, block = 256: groff[t][g] = flagged bytes of frame t in the groups before g, totals[t] = all
-// of them.  A wave loads the 64 byte counts of a group with one coalesced instruction and reduces them
-// with DPP; the (at most kScanChunk) group sums are scanned in LDS.
+// grid = T, block = 256: roff[t][r] = flagged bytes of frame t in the 16-tile ranges before r (4 per group),
+// totals[t] = all of them.  A wave loads the 64 byte counts of a group with one coalesced instruction and scans
+// them with DPP: lane 63 gives the group's sum, lanes 15 / 31 / 47 the bytes in front of its second, third and
+// fourth range; the (at most kScanChunk) group sums are scanned in LDS.
 // The workgroup that finishes last (ticket counter, reset for the next launch) also scans the frame totals
 // into offsets[0..T]: one launch and one dependent round trip less than a separate kernel.
-__global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t *groff, uint32_t *totals,
+__global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t *roff, uint32_t *totals,
                                                      uint32_t ntiles, uint32_t ngroups, uint32_t *ticket,
                                                      uint32_t *offsets) {
     static_assert(kXTiles == 64, "one wave reduces one group");
     __shared__ uint32_t s_sum[kScanChunk];
+    __shared__ uint32_t s_part[kScanChunk][3];
     __shared__ uint32_t s_scan[5];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t row = (size_t)blockIdx.x * ntiles;
-    uint32_t *out = groff + (size_t)blockIdx.x * ngroups;
+    uint32_t *out = roff + (size_t)blockIdx.x * ngroups * 4u;
     uint32_t carry = 0;
     for (uint32_t g0 = 0; g0 < ngroups; g0 += kScanChunk) {
         const uint32_t gn = min(kScanChunk, ngroups - g0);
@@ -349,7 +354,10 @@ __global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {
                 const uint32_t incl = (uint32_t)wave_inclusive_scan((int)z[k]);
-                if (lane == 63 && g + k < gn) s_sum[g + k] = incl;
+                if (g + k < gn) {
+                    if (lane == 63) s_sum[g + k] = incl;
+                    if ((lane & 15u) == 15u && lane < 48u) s_part[g + k][lane >> 4] = incl;
+                }
             }
         }
         __syncthreads();
@@ -365,10 +373,13 @@ __global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t
 #pragma unroll
         for (uint32_t i = 0; i < 4; i++) {
             const uint32_t idx = threadIdx.x * 4 + i;
-            if (idx < gn) out[g0 + idx] = acc;
+            if (idx < gn)
+                *reinterpret_cast<uint4 *>(out + 4 * (size_t)(g0 + idx)) =
+                    make_uint4(acc, acc + s_part[idx][0], acc + s_part[idx][1], acc + s_part[idx][2]);
             acc += v[i];
         }
         carry += total;
+        __syncthreads();   // s_part / s_sum are rewritten by the next chunk
     }
     // totals and the ticket are agent-scope atomics: the workgroups run on different XCDs, whose L2s are
     // not coherent for plain accesses (publish_then_take_ticket says how the two are ordered).
@@ -395,9 +406,9 @@ __global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t
 
 uint32_t expand_groups(uint32_t ntiles) { return (ntiles + kXTiles - 1) / kXTiles; }
 
-hipError_t launch_scan(const uint4 *meta, uint32_t *groff, uint32_t *totals, uint32_t ntiles,
+hipError_t launch_scan(const uint4 *meta, uint32_t *roff, uint32_t *totals, uint32_t ntiles,
                        int nframes, uint32_t *offsets, uint32_t *ticket, hipStream_t s) {
-    hipLaunchKernelGGL(k_scan_groups, dim3(nframes), dim3(256), 0, s, meta, groff, totals, ntiles,
+    hipLaunchKernelGGL(k_scan_groups, dim3(nframes), dim3(256), 0, s, meta, roff, totals, ntiles,
                        expand_groups(ntiles), ticket, offsets);
     return hipGetLastError();
 }
@@ -425,9 +436,14 @@ __device__ __forceinline__ void lds_handoff() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// Entries [first, first + count) of the wave, staged in LDS as (index relative to xs0) << 8 | difference, leave with
-// coalesced stores: one dword per index, and the differences as whole dwords too (byte stores only for the up to
-// three bytes before and after the dword-aligned body of the destination).
+// Entries [first, first + count) of the wave, staged in LDS as (index relative to xs0) << 8 | difference, leave four
+// to a lane: one ds_read_b128, one 16-byte store of the four indices and one dword of the four differences (gfx950
+// global stores need no alignment: the index section is dword aligned in the packed form and byte aligned on the
+// wire, the differences start at any byte).
+struct __attribute__((packed, aligned(4))) U32x4A4 { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) U32x4A1 { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) U32A1 { uint32_t x; };
+
 template <bool WIRE>
 __device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint32_t *stage, uint32_t first, uint32_t count,
                                               uint32_t xs0, uint32_t dst0, uint8_t *w_xs, uint8_t *w_df, size_t w_room) {
@@ -447,24 +463,24 @@ __device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint32_
 #if MI355_XABLATE == 4
     if (xs0 != 0xfffffff0u) n = 0;
 #endif
-    for (uint32_t i = lane; i < n; i += 64u) store_u32_unaligned(xsp + 4 * (size_t)i, xs0 + (stage[i] >> 8));
-    const uint32_t lead = (4u - (uint32_t)((uintptr_t)dfp & 3u)) & 3u;
-    const uint32_t head = lead < n ? lead : n;
-    const uint32_t body = (n - head) >> 2;
-    if (lane < head) dfp[lane] = (uint8_t)stage[lane];
-    for (uint32_t k = lane; k < body; k += 64u) {
-        const uint32_t *q = stage + head + 4 * k;
-        // the low bytes of four entries: v_perm picks byte 0 of two dwords at a time
-        const uint32_t lo = __builtin_amdgcn_perm(q[1], q[0], 0x0c0c0400u), hi = __builtin_amdgcn_perm(q[3], q[2], 0x04000c0cu);
-        *reinterpret_cast<uint32_t *>(dfp + head + 4 * (size_t)k) = lo | hi;
+    const uint32_t n4 = n >> 2;
+    for (uint32_t k = lane; k < n4; k += 64u) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(stage + 4 * k);
+        const uint32_t x0 = xs0 + (q.x >> 8), x1 = xs0 + (q.y >> 8), x2 = xs0 + (q.z >> 8), x3 = xs0 + (q.w >> 8);
+        if (WIRE) *reinterpret_cast<U32x4A1 *>(xsp + 16 * (size_t)k) = U32x4A1{x0, x1, x2, x3};
+        else *reinterpret_cast<U32x4A4 *>(xsp + 16 * (size_t)k) = U32x4A4{x0, x1, x2, x3};
+        // the low bytes of the four entries: v_perm picks byte 0 of two dwords at a time
+        const uint32_t lo = __builtin_amdgcn_perm(q.y, q.x, 0x0c0c0400u), hi = __builtin_amdgcn_perm(q.w, q.z, 0x04000c0cu);
+        *reinterpret_cast<U32A1 *>(dfp + 4 * (size_t)k) = U32A1{lo | hi};
     }
-    const uint32_t tail = head + 4 * body + lane;
-    if (tail < n) dfp[tail] = (uint8_t)stage[tail];
+    const uint32_t tail = 4u * n4 + lane;   // the up to three entries left
+    if (tail < n) {
+        const uint32_t v = stage[tail];
+        store_u32_unaligned(xsp + 4 * (size_t)tail, xs0 + (v >> 8));
+        dfp[tail] = (uint8_t)v;
+    }
 }
 
-#ifndef MI355_XTILES
-#define MI355_XTILES 16
-#endif
 #ifndef MI355_XROUNDS
 #define MI355_XROUNDS 3
 #endif
@@ -473,33 +489,42 @@ __device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint32_
 #ifndef MI355_XABLATE
 #define MI355_XABLATE 0
 #endif
-constexpr uint32_t kWTiles = MI355_XTILES;   // tiles per single-wave workgroup (16, 32 or 64: a divisor of kXTiles)
-constexpr uint32_t kWPerGroup = 64u / kWTiles;
+constexpr uint32_t kWTiles = 16;             // tiles per single-wave workgroup: one DPP row of lanes, a quarter of a scan group
 constexpr uint32_t kWStage = 1024;     // entries staged per wave = the most a round of 64 candidates can hold
 constexpr int kXRounds = MI355_XROUNDS;      // rounds of 64 candidates whose loads are requested together
 #ifndef MI355_XLIGHT
 #define MI355_XLIGHT 4
 #endif
 constexpr uint32_t kXLight = MI355_XLIGHT;   // lanes with more flagged bytes than this are expanded by 16 lanes
+constexpr int kXHeavyMax = 12;               // ... unless a round of 64 candidates holds more of them than this
 
 // What a wave needs before it can start on its item (frame t, tiles 16 sub .. 16 sub + 15).
 struct ItemPro {
-    uint4 m;          // lane L: meta word of tile L of the item's 64-tile group
+    uint4 m;          // lane L < 16: meta word of tile 16 sub + L
     uint32_t off_t;   // entries of the frames before t
-    uint32_t goff;    // entries of frame t before the group
+    uint32_t roff;    // entries of frame t before the item's tiles
     uint32_t n_t;     // WIRE: entries of frame t
 };
 
 template <bool WIRE>
 __device__ __forceinline__ ItemPro load_item(const ExpandArgs &a, uint32_t t, uint32_t sub, uint32_t ngroups, uint32_t lane) {
     ItemPro p;
-    const uint32_t group = sub / kWPerGroup, gtile = group * kXTiles + lane;
+    const uint32_t tile = sub * kWTiles + lane;
     p.m = make_uint4(0, 0, 0, 0);
-    if (gtile < a.ntiles) p.m = a.meta[(size_t)t * a.ntiles + gtile];
+    if (lane < kWTiles && tile < a.ntiles) p.m = a.meta[(size_t)t * a.ntiles + tile];
     p.off_t = a.offsets[t];
-    p.goff = a.groff[(size_t)t * ngroups + group];
+    p.roff = a.roff[(size_t)t * ngroups * 4u + sub];
     p.n_t = WIRE ? a.offsets[t + 1] - p.off_t : 0u;
     return p;
+}
+
+// inclusive scan inside the first 16 lanes (one DPP row)
+__device__ __forceinline__ int row_inclusive_scan(int v) {
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+    return v;
 }
 
 // grid = (ceil(W/16), T) single-wave workgroups: one item each (the hardware's dispatcher balances the items;
@@ -510,29 +535,26 @@ template <bool WIRE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_expand(const ExpandArgs a) {
     __shared__ uint8_t s_tile[kWTiles * 64];      // candidate of the wave -> its tile
     __shared__ uint2 s_tinfo[kWTiles];            // per tile: {byte offset of its candidate 0 in the code log - 4 * (candidates before the tile), byte offset of its first record}
-    __shared__ uint32_t s_stage[kWStage];         // (byte index relative to the wave's first tile) << 8 | difference
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[kWStage];   // (byte index relative to the wave's first tile) << 8 | difference
     const uint32_t lane = threadIdx.x;
     const uint32_t ngroups = (a.ntiles + kXTiles - 1) / kXTiles;
     const uint32_t t = blockIdx.y, sub = blockIdx.x;
     if (sub * kWTiles >= a.ntiles) return;   // grid.x is padded to a multiple of 8 (see launch_expand)
     const ItemPro cur = load_item<WIRE>(a, t, sub, ngroups, lane);
     {
-        const uint32_t q = sub % kWPerGroup, tile0 = sub * kWTiles;
+        const uint32_t tile0 = sub * kWTiles;
         const uint4 m = cur.m;   // {code offset, record offset, flagged bytes, candidates | multi << 16}
         size_t head = 0;
         if (WIRE) {
             head = 4 * (size_t)t + 5 * (size_t)cur.off_t;
             if (sub == 0 && lane == 0 && head + 4 <= a.capacity) store_u32_unaligned(a.wire + head, cur.n_t);
         }
-        // lane L <-> tile L of the group; lanes kWTiles * q .. kWTiles * (q + 1) - 1 are this wave's tiles
-        const bool mine = lane / kWTiles == q;
-        const uint32_t nc = mine ? (m.w & 0xffffu) : 0u;
-        const uint32_t rincl = (uint32_t)wave_inclusive_scan((int)nc);
-        const uint32_t bincl = (uint32_t)wave_inclusive_scan((int)m.z);
-        const uint32_t nrec = (uint32_t)__builtin_amdgcn_readlane((int)rincl, 63);
+        // lane L < 16 <-> tile L of the item
+        const uint32_t nc = m.w & 0xffffu;   // 0 in lanes >= 16
+        const uint32_t rincl = (uint32_t)row_inclusive_scan((int)nc);
+        const uint32_t nrec = (uint32_t)__builtin_amdgcn_readlane((int)rincl, (int)kWTiles - 1);
         if (nrec != 0) {
-            const uint32_t before = q ? (uint32_t)__builtin_amdgcn_readlane((int)bincl, (int)(kWTiles * q - 1u)) : 0u;
-            const uint32_t dst0 = cur.off_t + cur.goff + before;   // < 2^32: the batch total is below 2^32
+            const uint32_t dst0 = cur.off_t + cur.roff;   // < 2^32: the batch total is below 2^32
             const uint32_t rexcl = rincl - nc;                     // candidates of this wave before the lane's tile
             uint8_t *w_xs = nullptr, *w_df = nullptr;
             size_t w_room = 0;
@@ -546,13 +568,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #if MI355_XABLATE == 1
             if (dst0 == 0xfffffff0u) a.out_xs[0] = (int32_t)nrec;
 #else
-            if (mine) s_tinfo[lane % kWTiles] = make_uint2(m.x - 4u * rexcl, m.y);
+            if (lane < kWTiles) s_tinfo[lane] = make_uint2(m.x - 4u * rexcl, m.y);
             // which tile candidate r of the wave belongs to: tile i owns ranks rexcl_i .. rexcl_i + nc_i - 1
 #pragma unroll 4
             for (uint32_t i = 0; i < kWTiles; i++) {
-                const int L = (int)(kWTiles * q + i);
-                const uint32_t nci = (uint32_t)__builtin_amdgcn_readlane((int)nc, L);
-                const uint32_t rx = (uint32_t)__builtin_amdgcn_readlane((int)rexcl, L);
+                const uint32_t nci = (uint32_t)__builtin_amdgcn_readlane((int)nc, (int)i);
+                const uint32_t rx = (uint32_t)__builtin_amdgcn_readlane((int)rexcl, (int)i);
                 if (lane < nci) s_tile[rx + lane] = (uint8_t)i;
             }
             lds_handoff();   // the tables are read by other lanes than the ones that wrote them
@@ -624,10 +645,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     carry += round_total;
                     // lanes with more than kXLight flagged bytes (object edges among isolated bytes) would make the whole
                     // wave walk their bits: they are expanded by 16 lanes each afterwards, four at a time
-                    const uint64_t heavy = __ballot(cnt > kXLight);
+                    // -- unless the round holds more than kXHeavyMax of them (dense frames): then everybody walks, all
+                    // lanes busy for as many steps as the fullest lane has bytes
+                    uint64_t heavy = __ballot(cnt > kXLight);
+                    const uint32_t light_max = __builtin_popcountll(heavy) > kXHeavyMax ? 16u : kXLight;
+                    if (light_max == 16u) heavy = 0;
                     if (cnt == 1u) {
                         s_stage[e] = ((src16[k] + (uint32_t)__builtin_ctz(m16)) << 8) | ((code[k] >> 16) & 0xffu);   // kernels.cu:314-315
-                    } else if (cnt > 1u && cnt <= kXLight) {
+                    } else if (cnt > 1u && cnt <= light_max) {
                         uint32_t mm = m16, ee = e;
                         do {
                             const int b = __builtin_ctz(mm);
@@ -676,7 +701,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 }
 
 hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s) {
-    static_assert(64u % kWTiles == 0 && kWTiles >= 16, "a wave owns a whole fraction of a 64-tile group");
+    static_assert(kWTiles * 4u == kXTiles, "k_scan_groups writes four range prefixes per group");
     // Workgroups go to the 8 XCDs round-robin by linear id: with grid.x a multiple of 8 the workgroups of one
     // tile range land on the same XCD for every frame (the padding workgroups return at once).
     const uint32_t gx = (a.ntiles + kWTiles - 1) / kWTiles;

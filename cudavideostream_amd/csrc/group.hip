@@ -8,8 +8,11 @@
 // (E2) through the ordinary single-device entry points, concurrently, each on its own device and stream.
 //
 // The gather is a gather-v of (per-frame index, xs, diff) to one root:
-//   1. ncclAllGather of one count per rank (everybody learns every total; one host synchronisation, as the
-//      reference reads h_pos back before its copies, kernels.cu:507-508);
+//   1. ncclAllGather of four words per rank {entries of its batch, entries its buffers hold, the root's capacity,
+//      argument check}: everybody learns every total AND reaches the same verdict on the capacities before
+//      anything is sent -- a gather that cannot work fails on every rank, nobody is left sending to a root that
+//      has already returned (one host synchronisation, as the reference reads h_pos back before its copies,
+//      kernels.cu:507-508);
 //   2. inside one ncclGroupStart/End: every other rank ncclSend's its index, xs and diff to the root, the root
 //      posts the matching ncclRecv's at rank-ordered places -- up to 7 concurrent point-to-point transfers into
 //      the root over its 7 direct xGMI links, no ring;
@@ -102,8 +105,11 @@ struct Member {
     bool owned = false;
     int rank = 0;              // rank in the group
     ncclComm_t comm = nullptr;
-    uint32_t *d_counts = nullptr;   // [nranks] on the member's device: every rank's total of the batch being gathered
+    uint32_t *d_counts = nullptr;   // [nranks][kWords] on the member's device: what every rank published for the gather
+    uint32_t *d_send = nullptr;     // [kWords] this member's own words
+    uint32_t h_send[4] = {0, 0, 0, 0};
 };
+constexpr int kWords = 4;   // per rank: entries of its batch, its member capacity, the root's capacity, argument check
 
 }  // namespace
 
@@ -111,6 +117,7 @@ struct mi355_group {
     int nranks = 0;
     std::vector<Member> local;
     std::vector<uint32_t> h_counts;
+    std::vector<uint32_t> h_all;    // [nranks][kWords]
 };
 
 namespace {
@@ -149,6 +156,7 @@ void mi355_group_destroy(mi355_group *g) {
         }
         if (m.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m.comm);
         if (m.d_counts) (void)hipFree(m.d_counts);
+        if (m.d_send) (void)hipFree(m.d_send);
         if (m.owned) mi355_destroy(m.core);
     }
     delete g;
@@ -164,6 +172,7 @@ int mi355_group_create(const mi355_config *cfg, int ndev, const int *devices, mi
     g->nranks = ndev;
     g->local.resize(ndev);
     g->h_counts.resize(ndev);
+    g->h_all.resize((size_t)ndev * kWords);
     std::vector<int> devs(ndev);
     int rc = MI355_OK;
     for (int i = 0; i < ndev && !rc; i++) {
@@ -175,7 +184,8 @@ int mi355_group_create(const mi355_config *cfg, int ndev, const int *devices, mi
         m.owned = true;
         rc = mi355_create(&c, &m.core);
         if (!rc && hipSetDevice(devs[i]) != hipSuccess) rc = set_error(MI355_ERR_HIP, "hipSetDevice");
-        if (!rc && hipMalloc((void **)&m.d_counts, sizeof(uint32_t) * ndev) != hipSuccess) rc = set_error(MI355_ERR_HIP, "hipMalloc");
+        if (!rc && hipMalloc((void **)&m.d_counts, sizeof(uint32_t) * kWords * ndev) != hipSuccess) rc = set_error(MI355_ERR_HIP, "hipMalloc");
+        if (!rc && hipMalloc((void **)&m.d_send, sizeof(uint32_t) * kWords) != hipSuccess) rc = set_error(MI355_ERR_HIP, "hipMalloc");
     }
     if (!rc) {
         std::vector<ncclComm_t> comms(ndev);
@@ -198,12 +208,14 @@ int mi355_group_adopt_rank(mi355_core *core, int nranks, int rank, const void *i
     g->nranks = nranks;
     g->local.resize(1);
     g->h_counts.resize(nranks);
+    g->h_all.resize((size_t)nranks * kWords);
     Member &m = g->local[0];
     m.core = core;
     m.rank = rank;
     int rc = MI355_OK;
     if (hipSetDevice(core_device(core)) != hipSuccess) rc = set_error(MI355_ERR_HIP, "hipSetDevice");
-    if (!rc && hipMalloc((void **)&m.d_counts, sizeof(uint32_t) * nranks) != hipSuccess) rc = set_error(MI355_ERR_HIP, "hipMalloc");
+    if (!rc && hipMalloc((void **)&m.d_counts, sizeof(uint32_t) * kWords * nranks) != hipSuccess) rc = set_error(MI355_ERR_HIP, "hipMalloc");
+    if (!rc && hipMalloc((void **)&m.d_send, sizeof(uint32_t) * kWords) != hipSuccess) rc = set_error(MI355_ERR_HIP, "hipMalloc");
     if (!rc) {
         ncclUniqueId id;
         memcpy(&id, id128, sizeof id);
@@ -255,64 +267,94 @@ int mi355_group_synchronize(mi355_group *g) {
 }
 
 int mi355_group_gather(mi355_group *g, int root, int nframes, const void *const *d_offsets, const void *const *d_xs,
-                       const void *const *d_diff, void *d_root_offsets, void *d_root_xs, void *d_root_diff,
-                       size_t root_capacity, uint64_t *h_counts) {
+                       const void *const *d_diff, size_t member_capacity, void *d_root_offsets, void *d_root_xs,
+                       void *d_root_diff, size_t root_capacity, uint64_t *h_counts) {
     if (int rc = check_group(g)) return rc;
     if (root < 0 || root >= g->nranks) return set_error(MI355_ERR_INVALID, "root outside [0, ranks)");
     if (nframes < 0) return set_error(MI355_ERR_INVALID, "nframes < 0");
     if (!d_offsets || !d_xs || !d_diff) return set_error(MI355_ERR_INVALID, "null argument");
     Member *rootm = member_of_rank(g, root);
-    if (rootm && (!d_root_offsets || (root_capacity && (!d_root_xs || !d_root_diff))))
-        return set_error(MI355_ERR_INVALID, "the root is a member of this process: its buffers are needed");
+    // Arguments only this process can judge are folded into what the ranks exchange (word 3), so that a bad call
+    // on one rank fails the gather on EVERY rank instead of leaving the others with sends nobody receives.
+    const bool bad_root_args = rootm && (!d_root_offsets || (root_capacity && (!d_root_xs || !d_root_diff)));
     const int R = g->nranks;
-    // 1. every rank's total: offsets[nframes] of its batch
-    RCCL_TRY(g_rccl.GroupStart());
-    for (size_t i = 0; i < g->local.size(); i++) {
+    const uint32_t kMax = 0xFFFFFFFFu;
+    // 1. what every rank must know before anything is sent: per rank {entries of its batch = offsets[nframes],
+    //    entries its buffers hold, the root's capacity (the root's word only), argument check}
+    int rc = MI355_OK;
+    ncclResult_t ge = g_rccl.GroupStart();
+    if (ge != ncclSuccess) return rccl_fail("ncclGroupStart", ge);
+    for (size_t i = 0; i < g->local.size() && !rc; i++) {
         Member &m = g->local[i];
-        HIP_TRY_G(hipSetDevice(core_device(m.core)));
-        RCCL_TRY(g_rccl.AllGather((const uint32_t *)d_offsets[i] + nframes, m.d_counts, 1, ncclUint32, m.comm,
-                                  core_stream(m.core)));
+        hipStream_t s = core_stream(m.core);
+        m.h_send[0] = 0;
+        m.h_send[1] = member_capacity > kMax ? kMax : (uint32_t)member_capacity;
+        m.h_send[2] = m.rank == root ? (root_capacity > kMax ? kMax : (uint32_t)root_capacity) : 0u;
+        m.h_send[3] = m.rank == root && bad_root_args ? 1u : 0u;
+        hipError_t e = hipSetDevice(core_device(m.core));
+        if (e == hipSuccess) e = hipMemcpyAsync(m.d_send, m.h_send, sizeof m.h_send, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(m.d_send, (const uint32_t *)d_offsets[i] + nframes, sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) { rc = set_error(MI355_ERR_HIP, hipGetErrorString(e)); break; }
+        const ncclResult_t r = g_rccl.AllGather(m.d_send, m.d_counts, kWords, ncclUint32, m.comm, s);
+        if (r != ncclSuccess) rc = rccl_fail("ncclAllGather", r);
     }
-    RCCL_TRY(g_rccl.GroupEnd());
+    ge = g_rccl.GroupEnd();   // always closed: an open group would swallow every later RCCL call of the thread
+    if (!rc && ge != ncclSuccess) rc = rccl_fail("ncclGroupEnd", ge);
+    if (rc) return rc;
     {
         Member &m = g->local[0];
         HIP_TRY_G(hipSetDevice(core_device(m.core)));
-        HIP_TRY_G(hipMemcpyAsync(g->h_counts.data(), m.d_counts, sizeof(uint32_t) * R, hipMemcpyDeviceToHost, core_stream(m.core)));
+        HIP_TRY_G(hipMemcpyAsync(g->h_all.data(), m.d_counts, sizeof(uint32_t) * kWords * R, hipMemcpyDeviceToHost, core_stream(m.core)));
         HIP_TRY_G(hipStreamSynchronize(core_stream(m.core)));
     }
     std::vector<size_t> base(R + 1, 0);
+    bool member_overflow = false, bad_args = false;
     for (int r = 0; r < R; r++) {
-        base[r + 1] = base[r] + g->h_counts[r];
-        if (h_counts) h_counts[r] = g->h_counts[r];
+        const uint32_t *w = &g->h_all[(size_t)r * kWords];
+        g->h_counts[r] = w[0];
+        base[r + 1] = base[r] + w[0];
+        if (h_counts) h_counts[r] = w[0];
+        member_overflow |= w[0] > w[1];
+        bad_args |= w[3] != 0;
     }
-    if (rootm && base[R] > root_capacity) return set_error(MI355_ERR_INVALID, "root capacity below the gathered total");
+    const size_t root_cap = g->h_all[(size_t)root * kWords + 2];
+    // the same verdict on every rank: nothing has been sent yet, nobody waits for anybody
+    if (bad_args) return set_error(MI355_ERR_INVALID, "the root's buffers are missing (the root is a member of some process)");
+    if (member_overflow)
+        return set_error(MI355_ERR_INVALID, "a member's batch holds more entries than its buffers (member_capacity): "
+                                            "entries beyond the capacity were dropped, there is nothing to gather from");
+    if (base[R] > root_cap) return set_error(MI355_ERR_INVALID, "root capacity below the gathered total");
     // 2. index and payload travel point to point, all transfers of the step in one RCCL group
     const size_t row = (size_t)nframes + 1;
-    RCCL_TRY(g_rccl.GroupStart());
-    for (size_t i = 0; i < g->local.size(); i++) {
+    ge = g_rccl.GroupStart();
+    if (ge != ncclSuccess) return rccl_fail("ncclGroupStart", ge);
+    auto step = [&](ncclResult_t r, const char *what) { if (!rc && r != ncclSuccess) rc = rccl_fail(what, r); };
+    for (size_t i = 0; i < g->local.size() && !rc; i++) {
         Member &m = g->local[i];
-        HIP_TRY_G(hipSetDevice(core_device(m.core)));
+        if (hipSetDevice(core_device(m.core)) != hipSuccess) { rc = set_error(MI355_ERR_HIP, "hipSetDevice"); break; }
         hipStream_t s = core_stream(m.core);
         if (m.rank == root) {
-            for (int r = 0; r < R; r++) {
+            for (int r = 0; r < R && !rc; r++) {
                 if (r == root) continue;
                 const size_t c = g->h_counts[r];
-                RCCL_TRY(g_rccl.Recv((uint32_t *)d_root_offsets + (size_t)r * row, row, ncclUint32, r, m.comm, s));
+                step(g_rccl.Recv((uint32_t *)d_root_offsets + (size_t)r * row, row, ncclUint32, r, m.comm, s), "ncclRecv");
                 if (c) {
-                    RCCL_TRY(g_rccl.Recv((int32_t *)d_root_xs + base[r], c, ncclInt32, r, m.comm, s));
-                    RCCL_TRY(g_rccl.Recv((uint8_t *)d_root_diff + base[r], c, ncclUint8, r, m.comm, s));
+                    step(g_rccl.Recv((int32_t *)d_root_xs + base[r], c, ncclInt32, r, m.comm, s), "ncclRecv");
+                    step(g_rccl.Recv((uint8_t *)d_root_diff + base[r], c, ncclUint8, r, m.comm, s), "ncclRecv");
                 }
             }
         } else {
             const size_t c = g->h_counts[m.rank];
-            RCCL_TRY(g_rccl.Send(d_offsets[i], row, ncclUint32, root, m.comm, s));
+            step(g_rccl.Send(d_offsets[i], row, ncclUint32, root, m.comm, s), "ncclSend");
             if (c) {
-                RCCL_TRY(g_rccl.Send(d_xs[i], c, ncclInt32, root, m.comm, s));
-                RCCL_TRY(g_rccl.Send(d_diff[i], c, ncclUint8, root, m.comm, s));
+                step(g_rccl.Send(d_xs[i], c, ncclInt32, root, m.comm, s), "ncclSend");
+                step(g_rccl.Send(d_diff[i], c, ncclUint8, root, m.comm, s), "ncclSend");
             }
         }
     }
-    RCCL_TRY(g_rccl.GroupEnd());
+    ge = g_rccl.GroupEnd();
+    if (!rc && ge != ncclSuccess) rc = rccl_fail("ncclGroupEnd", ge);
+    if (rc) return rc;
     // 3. the root's own part
     if (rootm) {
         const size_t i = (size_t)(rootm - g->local.data());

@@ -34,7 +34,7 @@ struct ExpandArgs {
     const uint32_t *codes;
     const uint4 *rec;
     const uint4 *meta;        // [T][W]
-    const uint32_t *groff;    // [T][G]  flagged bytes of the frame before each group of 64 tiles (G = ceil(W/64))
+    const uint32_t *roff;     // [T][4G] flagged bytes of the frame before each range of 16 tiles (G = ceil(W/64) groups)
     const uint32_t *offsets;  // [T+1]   exclusive scan of the frame totals
     uint32_t ntiles;
     int32_t *out_xs;
@@ -109,7 +109,7 @@ int core_device(const ::mi355_core *c);
 // diff_pack.hip
 hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, hipStream_t s);
 uint32_t expand_groups(uint32_t ntiles);
-hipError_t launch_scan(const uint4 *meta, uint32_t *groff, uint32_t *totals, uint32_t ntiles,
+hipError_t launch_scan(const uint4 *meta, uint32_t *roff, uint32_t *totals, uint32_t ntiles,
                        int nframes, uint32_t *offsets, uint32_t *ticket /* zero between launches */,
                        hipStream_t s);
 hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s);

@@ -94,14 +94,16 @@ class CUDAGroup:
                                                         nframes, _ptr_array(d_offsets), _ptr_array(d_xs),
                                                         _ptr_array(d_diff), capacity))
 
-    def gather(self, root, nframes, d_offsets, d_xs, d_diff, d_root_offsets=None, d_root_xs=None,
+    def gather(self, root, nframes, d_offsets, d_xs, d_diff, member_capacity, d_root_offsets=None, d_root_xs=None,
                d_root_diff=None, root_capacity=0):
-        """Collective over all ranks.  Returns every rank's total (numpy uint64[nranks])."""
+        """Collective over all ranks.  member_capacity = entries the local members' d_xs / d_diff hold.  Returns
+        every rank's total (numpy uint64[nranks]); raises on EVERY rank when a member overflowed its buffers or the
+        root's capacity is below the gathered total (decided before anything is sent)."""
         counts = np.zeros(self.nranks, np.uint64)
         _l.check(self._lib.mi355_group_gather(self._h, int(root), int(nframes), _ptr_array(d_offsets),
-                                              _ptr_array(d_xs), _ptr_array(d_diff), _ptr(d_root_offsets),
-                                              _ptr(d_root_xs), _ptr(d_root_diff), int(root_capacity),
-                                              counts.ctypes.data_as(C.POINTER(C.c_uint64))))
+                                              _ptr_array(d_xs), _ptr_array(d_diff), int(member_capacity),
+                                              _ptr(d_root_offsets), _ptr(d_root_xs), _ptr(d_root_diff),
+                                              int(root_capacity), counts.ctypes.data_as(C.POINTER(C.c_uint64))))
         return counts
 
     def synchronize(self):

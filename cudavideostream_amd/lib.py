@@ -112,8 +112,8 @@ SYMBOLS = {
                                                C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                                C.POINTER(C.c_void_p), C.c_size_t]),
     "mi355_group_gather": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
-                                     C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
-                                     C.POINTER(C.c_uint64)]),
+                                     C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.POINTER(C.c_uint64)]),
     "mi355_group_synchronize": (C.c_int, [C.c_void_p]),
 }
 GROUP_ID_BYTES = 128   # MI355_GROUP_ID_BYTES

@@ -279,12 +279,19 @@ int mi355_group_diff_pairs_batch(mi355_group *group, const void *const *d_cur, c
 /* Gather-v of the members' batch outputs to rank `root`: collective over ALL ranks of the group (every process
  * calls it with its local members' arrays).  On the root's device: d_root_offsets[rank][0..nframes] = that
  * rank's own exclusive scan, d_root_xs / d_root_diff = the ranks' entries back to back in rank order (rank r at
- * the sum of the counts before it; root_capacity entries).  h_counts[rank] receives every rank's total in every
+ * the sum of the counts before it; root_capacity entries).  member_capacity = the entries every local member's
+ * d_xs / d_diff hold (the `capacity` its batch ran with).  h_counts[rank] receives every rank's total in every
  * process (one host synchronisation, kernels.cu:507-508 reads its count back the same way); the transfers
- * themselves are asynchronous on the members' streams.  d_root_* are ignored where the root is not local. */
+ * themselves are asynchronous on the members' streams.  d_root_* / root_capacity are ignored where the root is
+ * not local.
+ * Failures that concern the whole exchange are decided collectively, BEFORE anything is sent, and reported on
+ * every rank alike (MI355_ERR_INVALID): a member whose batch overflowed its buffers (offsets[nframes] >
+ * member_capacity: the entries beyond were dropped, there is nothing to send), a gathered total above the root's
+ * capacity, missing root buffers.  No rank is left waiting for another. */
 int mi355_group_gather(mi355_group *group, int root, int nframes, const void *const *d_offsets,
-                       const void *const *d_xs, const void *const *d_diff, void *d_root_offsets, void *d_root_xs,
-                       void *d_root_diff, size_t root_capacity, uint64_t *h_counts);
+                       const void *const *d_xs, const void *const *d_diff, size_t member_capacity,
+                       void *d_root_offsets, void *d_root_xs, void *d_root_diff, size_t root_capacity,
+                       uint64_t *h_counts);
 int mi355_group_synchronize(mi355_group *group);
 
 /* ---- measurement ---------------------------------------------------------------------------------

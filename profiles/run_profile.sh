@@ -16,11 +16,10 @@ sha256sum $ROOT/cudavideostream_amd/libmi355diff.so > $OUT/lib.sha256
 ARGS="bench.py --steps $STEPS --warmup 2 --no-cpu --no-pair --no-host-path --no-filters"
 cd $ROOT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || echo "trace failed"
-# counter passes run the C++ harness (same workload, same library).  The same pass on bench.py itself is
-# attempted once and its log kept (profiles/<tag>_pmc_under_python.log): round 1 saw the counter-collection
-# interposer crash inside PyTorch's own kernels.
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_py -- python3 $ARGS > $OUT/fetch_py.log 2>&1; echo "exit code $?" >> $OUT/fetch_py.log
-tail -40 $OUT/fetch_py.log > $ROOT/gpurun_out/${TAG}_pmc_under_python.log
+# counter passes run the C++ harness (same workload, same library, no Python).  They are NOT attempted on
+# `python3 bench.py` any more: that pass crashed in every round (profiles/r02{g,h,i}_pmc_under_python.log) and its
+# cause is known -- see profiles/README.md, "counter passes under PyTorch": the process then holds two HSA/HIP
+# runtimes (PyTorch's bundled ROCm 7.0 copies and the profiler's /opt/rocm 7.2 ones).
 DB="tools/diffbench --steps $STEPS --warmup 2"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $DB > $OUT/fetch.log 2>&1 || echo "fetch failed"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $DB > $OUT/write.log 2>&1 || echo "write failed"

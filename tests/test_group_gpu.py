@@ -44,7 +44,7 @@ def test_adopted_rank_gathers_its_own_stream(po):
             r_df = torch.full((T * n,), 0x77, dtype=torch.uint8, device=DEV)
             torch.cuda.synchronize()
             grp.diff_stream_batch([d_fr], T, [d_off], [d_xs], [d_df], T * n, stride=n)
-            counts = grp.gather(0, T, [d_off], [d_xs], [d_df], r_off, r_xs, r_df, T * n)
+            counts = grp.gather(0, T, [d_off], [d_xs], [d_df], T * n, r_off, r_xs, r_df, T * n)
             grp.synchronize()
             tot = int(eo[-1])
             assert counts.tolist() == [tot]
@@ -54,7 +54,7 @@ def test_adopted_rank_gathers_its_own_stream(po):
             assert np.array_equal(core.get_state(), est)
             # capacity below the gathered total is an error, not a truncation
             with pytest.raises(lib.Mi355Error):
-                grp.gather(0, T, [d_off], [d_xs], [d_df], r_off, r_xs, r_df, tot - 1)
+                grp.gather(0, T, [d_off], [d_xs], [d_df], T * n, r_off, r_xs, r_df, tot - 1)
 
 
 def test_group_in_one_process_over_the_visible_devices(po):
@@ -80,7 +80,7 @@ def test_group_in_one_process_over_the_visible_devices(po):
         torch.cuda.synchronize()
         grp.diff_stream_batch([b["fr"] for b in bufs], T, [b["off"] for b in bufs], [b["xs"] for b in bufs],
                               [b["df"] for b in bufs], T * n, stride=n)
-        counts = grp.gather(0, T, [b["off"] for b in bufs], [b["xs"] for b in bufs], [b["df"] for b in bufs],
+        counts = grp.gather(0, T, [b["off"] for b in bufs], [b["xs"] for b in bufs], [b["df"] for b in bufs], T * n,
                             r_off, r_xs, r_df, ndev * T * n)
         grp.synchronize()
         at = 0
@@ -159,7 +159,7 @@ with CUDAGroup.create(w, h, ndev, devices=[0] * ndev, max_batch=T) as grp:
     r_df = torch.zeros(ndev * T * n, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     grp.diff_stream_batch([b["fr"] for b in bufs], T, [b["off"] for b in bufs], [b["xs"] for b in bufs], [b["df"] for b in bufs], T * n, stride=n)
-    counts = grp.gather(root, T, [b["off"] for b in bufs], [b["xs"] for b in bufs], [b["df"] for b in bufs], r_off, r_xs, r_df, ndev * T * n)
+    counts = grp.gather(root, T, [b["off"] for b in bufs], [b["xs"] for b in bufs], [b["df"] for b in bufs], T * n, r_off, r_xs, r_df, ndev * T * n)
     grp.synchronize()
     at = 0
     for r in range(ndev):
@@ -179,3 +179,97 @@ def test_three_ranks_against_the_oracle(mock_rccl):
     code = CHILD % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=mock_rccl, cwd=ROOT)
     assert out.returncode == 0 and "GROUP-OK" in out.stdout, out.stderr[-2000:]
+
+
+# ---- one member per process, with threads standing in for the processes ------------------------------------------------
+# bench.py under torch.distributed.run has ONE member per process (mi355_group_adopt_rank).  What can go wrong there and
+# cannot in the one-process form: a rank that returns early while its peers go on to send.  The mock's threaded shape
+# (ncclCommInitRank with nranks > 1: a rank per thread, a group's end blocks until the peers have posted their side, a
+# partner that never comes is an error after MOCK_RCCL_TIMEOUT_S) runs exactly that protocol on the one GPU.
+CHILD_THREADS = r"""
+import sys, threading
+import numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+from cudavideostream_amd import CUDACore, lib, synth
+from cudavideostream_amd.group import CUDAGroup, unique_id
+from oracle import pyoracle as po
+R, root, w, h, T = 3, 1, 96, 54, 6
+n = 3 * w * h
+ident = unique_id()
+want, outcome, roots = {}, {}, {}
+barrier = threading.Barrier(R)
+
+def rank_main(r):
+    try:
+        base, frames = synth.webcam_stream(T, w, h, seed=90 + r)
+        want[r] = po.diff_stream(frames, base)
+        tot = int(want[r][0][-1])
+        with CUDACore(w, h, max_batch=T, sample_mat_data=base) as core:
+            with CUDAGroup.adopt(core, R, r, ident) as grp:
+                d_fr = torch.from_numpy(np.ascontiguousarray(frames)).cuda()
+                d_off = torch.zeros(T + 1, dtype=torch.int32, device="cuda")
+                d_xs = torch.zeros(T * n, dtype=torch.int32, device="cuda")
+                d_df = torch.zeros(T * n, dtype=torch.uint8, device="cuda")
+                r_off = torch.zeros((R, T + 1), dtype=torch.int32, device="cuda") if r == root else None
+                r_xs = torch.full((R * T * n,), -9, dtype=torch.int32, device="cuda") if r == root else None
+                r_df = torch.zeros(R * T * n, dtype=torch.uint8, device="cuda") if r == root else None
+                torch.cuda.synchronize()
+                grp.diff_stream_batch([d_fr], T, [d_off], [d_xs], [d_df], T * n, stride=n)
+                res = []
+                # (1) the root's capacity is one entry short: EVERY rank must get the error, nobody may wait
+                barrier.wait()
+                try:
+                    grp.gather(root, T, [d_off], [d_xs], [d_df], T * n, r_off, r_xs, r_df, (sum_tot[0] - 1) if r == root else 0)
+                    res.append("no error")
+                except lib.Mi355Error as e:
+                    res.append("capacity" if "root capacity" in str(e) else "other: " + str(e))
+                # (2) rank 2 claims buffers smaller than its batch: every rank fails alike
+                barrier.wait()
+                try:
+                    grp.gather(root, T, [d_off], [d_xs], [d_df], (tot - 1) if r == 2 else T * n, r_off, r_xs, r_df, R * T * n if r == root else 0)
+                    res.append("no error")
+                except lib.Mi355Error as e:
+                    res.append("member" if "member_capacity" in str(e) else "other: " + str(e))
+                # (3) and the group is still usable: the real gather
+                barrier.wait()
+                counts = grp.gather(root, T, [d_off], [d_xs], [d_df], T * n, r_off, r_xs, r_df, R * T * n if r == root else 0)
+                grp.synchronize()
+                res.append([int(c) for c in counts])
+                if r == root:
+                    roots["off"], roots["xs"], roots["df"] = r_off.cpu().numpy().view(np.uint32), r_xs.cpu().numpy(), r_df.cpu().numpy()
+                barrier.wait()   # nobody tears its communicator down while a peer is still inside the gather
+                outcome[r] = res
+    except Exception as e:   # noqa: BLE001
+        outcome[r] = ["exception: " + repr(e)]
+        barrier.abort()
+
+# the oracle's totals are needed by the root before the threads start
+sum_tot = [0]
+for r in range(R):
+    base, frames = synth.webcam_stream(T, w, h, seed=90 + r)
+    sum_tot[0] += int(po.diff_stream(frames, base)[0][-1])
+threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(R)]
+for t in threads: t.start()
+for t in threads: t.join(timeout=200)
+assert not any(t.is_alive() for t in threads), "a rank hangs"
+tots = [int(want[r][0][-1]) for r in range(R)]
+for r in range(R):
+    assert outcome[r] == ["capacity", "member", tots], (r, outcome[r])
+at = 0
+for r in range(R):
+    eo, exs, edf, _ = want[r]
+    assert np.array_equal(roots["off"][r], eo)
+    assert np.array_equal(roots["xs"][at:at + tots[r]], exs) and np.array_equal(roots["df"][at:at + tots[r]], edf)
+    at += tots[r]
+print("THREADS-OK")
+"""
+
+
+def test_one_member_per_process_protocol_with_threads(mock_rccl):
+    """Three ranks, one per thread (the one-member-per-process form): a root capacity that is too small and a member
+    whose batch overflowed are reported on EVERY rank, before anything is sent; the gather that follows delivers the
+    oracle's streams at root 1."""
+    code = CHILD_THREADS % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=400,
+                         env=dict(mock_rccl, MOCK_RCCL_TIMEOUT_S="30"), cwd=ROOT)
+    assert out.returncode == 0 and "THREADS-OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

@@ -78,7 +78,7 @@ int main(int argc, char **argv) {
 
     OK(mi355_group_diff_stream_batch(grp, d_frames.data(), n, T, d_off.data(), d_xs.data(), d_df.data(), cap));
     std::vector<uint64_t> counts(ndev);
-    OK(mi355_group_gather(grp, root, T, d_off.data(), d_xs.data(), d_df.data(), r_off, r_xs, r_df, rcap, counts.data()));
+    OK(mi355_group_gather(grp, root, T, d_off.data(), d_xs.data(), d_df.data(), cap, r_off, r_xs, r_df, rcap, counts.data()));
     OK(mi355_group_synchronize(grp));
 
     // what the root received against what every rank holds
