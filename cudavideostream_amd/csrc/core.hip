@@ -109,9 +109,25 @@ struct mi355_core {
     int64_t next_ticket = 0;
     hipStream_t up_stream = nullptr, down_stream = nullptr;
 
-    // timing: ring of event sets {before pack, after pack, after scan, after expand}, harvested lazily so
-    // that timed batches still queue back to back
-    static constexpr int kEvRing = 32, kEvPer = 4;
+    // Pipelined batches (own stream only): the index and the expansion of batch k run on `side` beside the pack
+    // kernel of batch k + 1 on the core's stream.  Two sets of logs, used alternately; set[0] is {rec, codes, meta,
+    // groff, totals} above, set[1] is made when the mode is first used.
+    struct LogSet {
+        uint4 *rec = nullptr, *meta = nullptr;
+        uint32_t *codes = nullptr, *groff = nullptr, *totals = nullptr;
+        hipEvent_t packed = nullptr, expanded = nullptr;   // pack kernel done (main) / expansion done (side)
+        bool in_use = false;                                // `expanded` has been recorded at least once
+    };
+    LogSet set[2];
+    int flip = 0;
+    hipStream_t side = nullptr;
+    hipEvent_t side_done = nullptr;   // == the `expanded` event of the last pipelined batch, or null: nothing pending
+    bool pipeline_ok = true;          // false: MI355_PIPELINE=0, or the second set could not be allocated
+    uint32_t k1_blocks = 0;           // pipelined batches: workgroups of the pack kernel (0 = one tile per wave)
+
+    // timing: ring of event sets {before pack, after pack, before scan, after scan, after expand}, harvested lazily
+    // so that timed batches still queue back to back
+    static constexpr int kEvRing = 32, kEvPer = 5;
     bool timing = false;
     hipEvent_t ev[kEvRing][kEvPer] = {};
     int ev_head = 0, ev_count = 0;  // oldest pending slot, number pending
@@ -121,7 +137,11 @@ struct mi355_core {
 
 namespace mi355 {
 int set_error(int code, const char *what) { return fail(code, what); }
-hipStream_t core_stream(const ::mi355_core *c) { return c->stream; }
+hipStream_t core_stream(::mi355_core *c) {   // for work other translation units enqueue: after the last pipelined batch
+    if (c->side_done && hipSetDevice(c->device) == hipSuccess && hipStreamWaitEvent(c->stream, c->side_done, 0) == hipSuccess)
+        c->side_done = nullptr;
+    return c->stream;
+}
 int core_device(const ::mi355_core *c) { return c->device; }
 }  // namespace mi355
 
@@ -135,21 +155,28 @@ int dev_alloc(mi355_core *c, T **p, size_t count) {
     return MI355_OK;
 }
 
-int use_device(const mi355_core *c) {
+// Every entry point starts here.  join: whatever the entry point enqueues on the core's stream (or waits for) comes
+// after the expansion of the last pipelined batch, which runs on the side stream; only the pipelined batch path
+// itself passes false (it orders its own kernels with events).
+int use_device(mi355_core *c, bool join = true) {
     HIP_TRY(hipSetDevice(c->device));
+    if (join && c->side_done) {
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->side_done, 0));
+        c->side_done = nullptr;
+    }
     return MI355_OK;
 }
 
-// Fold pending event triplets into the sums: all of them (blocking) or only until `keep` remain.
+// Fold pending event sets into the sums: all of them (blocking) or only until `keep` remain.
 int harvest_timing(mi355_core *c, int keep = 0) {
     while (c->ev_count > keep) {
         hipEvent_t *e = c->ev[c->ev_head];
-        HIP_TRY(hipEventSynchronize(e[3]));
+        HIP_TRY(hipEventSynchronize(e[4]));
         float a = 0, b = 0, d = 0, t = 0;
         HIP_TRY(hipEventElapsedTime(&a, e[0], e[1]));
-        HIP_TRY(hipEventElapsedTime(&b, e[1], e[2]));
-        HIP_TRY(hipEventElapsedTime(&d, e[2], e[3]));
-        HIP_TRY(hipEventElapsedTime(&t, e[0], e[3]));
+        HIP_TRY(hipEventElapsedTime(&b, e[2], e[3]));
+        HIP_TRY(hipEventElapsedTime(&d, e[3], e[4]));
+        HIP_TRY(hipEventElapsedTime(&t, e[0], e[4]));   // the batch's way through the path (batches overlap when pipelined)
         c->ms_pack += a;
         c->ms_scan += b;
         c->ms_expand += d;
@@ -311,10 +338,48 @@ int run_fused(mi355_core *c, const void *d_cur, size_t stride, int nframes, void
 }
 #endif
 
+// The second set of logs and the side stream of the pipelined mode, made when it is first used.
+int setup_pipeline(mi355_core *c) {
+    if (c->side || !c->pipeline_ok) return MI355_OK;
+    const char *env = getenv("MI355_PIPELINE");
+    if (env && env[0] == '0') { c->pipeline_ok = false; return MI355_OK; }
+    if (const char *b = getenv("MI355_K1_BLOCKS")) c->k1_blocks = (uint32_t)atoi(b);   // tuning knob (tools/, profiles/)
+    const size_t T = (size_t)c->cfg.max_batch, W = c->ntiles;
+    mi355_core::LogSet &s0 = c->set[0], &s1 = c->set[1];
+    s0.rec = c->rec; s0.codes = c->codes; s0.meta = c->meta; s0.groff = c->groff; s0.totals = c->totals;
+    bool ok = hipMalloc((void **)&s1.rec, T * W * 1024) == hipSuccess;
+    ok = ok && hipMalloc((void **)&s1.codes, code_chunks(T) * W * 1024) == hipSuccess;
+    ok = ok && hipMalloc((void **)&s1.meta, T * W * 16) == hipSuccess;
+    ok = ok && hipMalloc((void **)&s1.groff, T * expand_groups(c->ntiles) * 16) == hipSuccess;
+    ok = ok && hipMalloc((void **)&s1.totals, (T + 1) * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(s1.totals, 0, (T + 1) * sizeof(uint32_t)) == hipSuccess;   // the scan kernel's ticket
+    ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && ok; i++) {
+        ok = hipEventCreateWithFlags(&c->set[i].packed, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->set[i].expanded, hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) {   // not an error: the batches then run one after the other, as with a caller's stream
+        (void)hipGetLastError();
+        void *ptrs[] = {s1.rec, s1.codes, s1.meta, s1.groff, s1.totals};
+        for (void *p : ptrs) if (p) (void)hipFree(p);
+        s1 = mi355_core::LogSet{};
+        if (c->side) { (void)hipStreamDestroy(c->side); c->side = nullptr; }
+        c->pipeline_ok = false;
+        return MI355_OK;
+    }
+    c->workspace += T * W * 1024 + code_chunks(T) * W * 1024 + T * W * 16 + T * expand_groups(c->ntiles) * 16 + (T + 1) * 4;
+    return MI355_OK;
+}
+
 // d_wire != nullptr: the expander writes the sender's byte stream (capacity in bytes) instead of d_xs/d_diff.
+// pipelined: a public batch entry point on the core's OWN stream -- the index and the expansion run on the side
+// stream beside the next batch's pack kernel (which needs only the state, carried on the core's stream, and a free
+// set of logs); completion is what mi355_synchronize / any other entry point waits for (use_device joins).  With a
+// caller's stream (mi355_set_stream) everything stays on that stream, in order: a caller who enqueues its own
+// consumers there must find the batch complete.
 int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, size_t stride,
               int nframes, void *d_offsets, void *d_xs, void *d_diff, size_t capacity,
-              void *d_wire = nullptr) {
+              void *d_wire = nullptr, bool pipelined = false) {
     if (!c) return fail(MI355_ERR_INVALID, "null core");
     if (nframes < 0 || nframes > c->cfg.max_batch)
         return fail(MI355_ERR_INVALID, "nframes outside [0, max_batch]");
@@ -323,7 +388,17 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
         return fail(MI355_ERR_INVALID, "null frame pointer");
     if (nframes > 0 && stride < c->n) return fail(MI355_ERR_INVALID, "stride_bytes < frame bytes");
     if (capacity > 0 && !d_wire && (!d_xs || !d_diff)) return fail(MI355_ERR_INVALID, "null output pointer");
-    if (int rc = use_device(c)) return rc;
+    pipelined = pipelined && c->stream == c->own_stream && c->pipeline_ok && nframes > 0 && c->n > 0;
+#if MI355_EXPERIMENTS
+    pipelined = pipelined && !c->fused && !c->chain;
+#endif
+    if (pipelined) {
+        if (int rc = use_device(c, false)) return rc;
+        if (int rc = setup_pipeline(c)) return rc;
+        pipelined = c->pipeline_ok;
+    }
+    if (!pipelined)
+        if (int rc = use_device(c)) return rc;
     if (nframes == 0 || c->n == 0) {
         HIP_TRY(hipMemsetAsync(d_offsets, 0, sizeof(uint32_t) * ((size_t)nframes + 1), c->stream));
         if (d_wire) {   // empty frames still have their headers {n = 0}
@@ -336,8 +411,15 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     if (c->timing) {
         if (int rc = harvest_timing(c, mi355_core::kEvRing - 1)) return rc;
         tev = c->ev[(c->ev_head + c->ev_count) % mi355_core::kEvRing];
-        HIP_TRY(hipEventRecord(tev[0], c->stream));
     }
+    // the set of logs this batch writes; a pipelined batch may only start once the expansion that last read the
+    // set (two batches ago) is done
+    mi355_core::LogSet one;
+    one.rec = c->rec; one.codes = c->codes; one.meta = c->meta; one.groff = c->groff; one.totals = c->totals;
+    mi355_core::LogSet &ls = pipelined ? c->set[c->flip] : one;
+    hipStream_t tail = pipelined ? c->side : c->stream;   // where the index and the expansion run
+    if (pipelined && ls.in_use) HIP_TRY(hipStreamWaitEvent(c->stream, ls.expanded, 0));
+    if (tev) HIP_TRY(hipEventRecord(tev[0], c->stream));
 #if MI355_EXPERIMENTS
     if (c->fused && !pair && !d_wire && (((uintptr_t)d_cur | stride) & 15u) == 0) {
         if (int rc = run_fused(c, d_cur, stride, nframes, d_offsets, d_xs, d_diff, capacity)) return rc;
@@ -365,33 +447,44 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     a.nframes = nframes;
     a.thr = c->cfg.threshold;
     a.ntiles = c->ntiles;
-    a.rec = c->rec;
-    a.codes = c->codes;
+    a.rec = ls.rec;
+    a.codes = ls.codes;
     a.codes_bytes = (uint32_t)(code_chunks((size_t)c->cfg.max_batch) * c->ntiles * 1024u);
-    a.meta = c->meta;
+    a.meta = ls.meta;
     a.rec_bytes = (uint32_t)((size_t)c->cfg.max_batch * c->ntiles * 1024u);
     a.meta_bytes = (uint32_t)((size_t)c->cfg.max_batch * c->ntiles * 16u);
     const bool aligned = (((uintptr_t)d_cur | (uintptr_t)d_prev | stride) & 15u) == 0;
-    HIP_TRY(launch_diff_pack(a, pair, aligned, c->stream));
+    HIP_TRY(launch_diff_pack(a, pair, aligned, pipelined ? c->k1_blocks : 0u, c->stream));
     if (tev) HIP_TRY(hipEventRecord(tev[1], c->stream));
-    HIP_TRY(launch_scan(c->meta, c->groff, c->totals, c->ntiles, nframes, (uint32_t *)d_offsets,
-                        c->totals + c->cfg.max_batch, c->stream));
-    if (tev) HIP_TRY(hipEventRecord(tev[2], c->stream));
+    if (pipelined) {
+        HIP_TRY(hipEventRecord(ls.packed, c->stream));
+        HIP_TRY(hipStreamWaitEvent(tail, ls.packed, 0));
+    }
+    if (tev) HIP_TRY(hipEventRecord(tev[2], tail));
+    HIP_TRY(launch_scan(ls.meta, ls.groff, ls.totals, c->ntiles, nframes, (uint32_t *)d_offsets,
+                        ls.totals + c->cfg.max_batch, tail));
+    if (tev) HIP_TRY(hipEventRecord(tev[3], tail));
     ExpandArgs g{};
-    g.rec = c->rec;
-    g.codes = c->codes;
-    g.meta = c->meta;
-    g.roff = c->groff;
+    g.rec = ls.rec;
+    g.codes = ls.codes;
+    g.meta = ls.meta;
+    g.roff = ls.groff;
     g.offsets = (const uint32_t *)d_offsets;
     g.ntiles = c->ntiles;
     g.out_xs = (int32_t *)d_xs;
     g.out_diff = (uint8_t *)d_diff;
     g.wire = (uint8_t *)d_wire;
     g.capacity = capacity;
-    HIP_TRY(launch_expand(g, nframes, c->stream));
+    HIP_TRY(launch_expand(g, nframes, tail));
     if (tev) {
-        HIP_TRY(hipEventRecord(tev[3], c->stream));
+        HIP_TRY(hipEventRecord(tev[4], tail));
         c->ev_count += 1;
+    }
+    if (pipelined) {
+        HIP_TRY(hipEventRecord(ls.expanded, tail));
+        ls.in_use = true;
+        c->side_done = ls.expanded;
+        c->flip ^= 1;
     }
     return MI355_OK;
 }
@@ -471,7 +564,18 @@ void mi355_destroy(mi355_core *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->nslots) (void)mi355_pipe_close(c);
+    if (c->side) (void)hipStreamSynchronize(c->side);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    {
+        mi355_core::LogSet &s1 = c->set[1];
+        void *more[] = {s1.rec, s1.codes, s1.meta, s1.groff, s1.totals};
+        for (void *p : more) if (p) (void)hipFree(p);
+        for (auto &ls : c->set) {
+            if (ls.packed) (void)hipEventDestroy(ls.packed);
+            if (ls.expanded) (void)hipEventDestroy(ls.expanded);
+        }
+        if (c->side) (void)hipStreamDestroy(c->side);
+    }
     void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->codes, c->meta, c->groff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
                     c->lut, c->glyphs, c->kxk, c->gray1, c->red_bounds, c->f_wgsum, c->f_sync, c->f_spill, c->f_ovf, c->f_ready, c->c_desc, c->c_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -574,19 +678,19 @@ int mi355_set_glyphs(mi355_core *c, const uint8_t *chars_px, int nglyphs, int gl
 
 int mi355_diff_stream_batch(mi355_core *c, const void *d_frames, size_t stride_bytes, int nframes,
                             void *d_offsets, void *d_xs, void *d_diff, size_t capacity) {
-    return run_batch(c, false, d_frames, nullptr, stride_bytes, nframes, d_offsets, d_xs, d_diff, capacity);
+    return run_batch(c, false, d_frames, nullptr, stride_bytes, nframes, d_offsets, d_xs, d_diff, capacity, nullptr, true);
 }
 
 int mi355_diff_pairs_batch(mi355_core *c, const void *d_cur, const void *d_prev, size_t stride_bytes,
                            int nframes, void *d_offsets, void *d_xs, void *d_diff, size_t capacity) {
-    return run_batch(c, true, d_cur, d_prev, stride_bytes, nframes, d_offsets, d_xs, d_diff, capacity);
+    return run_batch(c, true, d_cur, d_prev, stride_bytes, nframes, d_offsets, d_xs, d_diff, capacity, nullptr, true);
 }
 
 int mi355_diff_stream_wire_batch(mi355_core *c, const void *d_frames, size_t stride_bytes, int nframes,
                                  void *d_offsets, void *d_wire, size_t capacity_bytes) {
     if (!d_wire) return fail(MI355_ERR_INVALID, "null d_wire");
     return run_batch(c, false, d_frames, nullptr, stride_bytes, nframes, d_offsets, nullptr, nullptr,
-                     capacity_bytes, d_wire);
+                     capacity_bytes, d_wire, true);
 }
 
 size_t mi355_wire_bytes(int nframes, uint64_t entries) { return 4 * (size_t)nframes + 5 * (size_t)entries; }
@@ -724,7 +828,8 @@ int mi355_red_stream_batch(mi355_core *c, const void *d_offsets, const void *d_x
     if (!d_offsets || !d_xs || !d_frames) return fail(MI355_ERR_INVALID, "null argument");
     if (stride_bytes < c->n) return fail(MI355_ERR_INVALID, "stride_bytes < frame bytes");
     if (int rc = use_device(c)) return rc;
-    if (nframes > c->cfg.max_batch) return fail(MI355_ERR_INVALID, "nframes outside [0, max_batch]");
+    // only the cleared form needs per-frame scratch (slice bounds), which is sized for max_batch frames
+    if (clear && nframes > c->cfg.max_batch) return fail(MI355_ERR_INVALID, "nframes outside [0, max_batch]");
     if (clear && !c->red_bounds)
         if (int rc = dev_alloc(c, &c->red_bounds, (size_t)c->cfg.max_batch * red_bounds_per_frame(c->n))) return rc;
     HIP_TRY(launch_red_stream((uint8_t *)d_frames, (const uint32_t *)d_offsets, (const int32_t *)d_xs, c->n, clear != 0,

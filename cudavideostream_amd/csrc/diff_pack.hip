@@ -255,22 +255,26 @@ __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint
 template <bool PAIR, bool ALIGNED>
 __global__ __launch_bounds__(256) void k_diff_pack(const PackArgs a) {
     const int lane = threadIdx.x & 63;
-    const uint32_t tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (tile >= a.ntiles) return;  // wave-uniform
-    const uint32_t tile_off = tile * kTileBytes;
-    const uint32_t byte_off = tile_off + (uint32_t)lane * 16u;
-    // wave-uniform choice: every lane of a full, aligned tile takes the vector path
-    if (ALIGNED && tile_off + kTileBytes <= a.n) {
-        pack_tile<PAIR, true>(a, tile, byte_off, 16, lane);
-    } else {
-        const int valid = byte_off < a.n ? (int)min(16u, a.n - byte_off) : 0;
-        pack_tile<PAIR, false>(a, tile, byte_off, valid, lane);
+    // one tile per wave when the grid covers the frame (the default); a smaller grid walks the tiles with its stride
+    // (pipelined batches leave wave slots to the expansion of the batch before, core.hip)
+    for (uint32_t tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); tile < a.ntiles; tile += gridDim.x * kWavesPerBlock) {
+        const uint32_t tile_off = tile * kTileBytes;
+        const uint32_t byte_off = tile_off + (uint32_t)lane * 16u;
+        // wave-uniform choice: every lane of a full, aligned tile takes the vector path
+        if (ALIGNED && tile_off + kTileBytes <= a.n) {
+            pack_tile<PAIR, true>(a, tile, byte_off, 16, lane);
+        } else {
+            const int valid = byte_off < a.n ? (int)min(16u, a.n - byte_off) : 0;
+            pack_tile<PAIR, false>(a, tile, byte_off, valid, lane);
+        }
     }
 }
 
-hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, hipStream_t s) {
+hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, uint32_t max_blocks, hipStream_t s) {
     const dim3 block(64 * kWavesPerBlock);
-    const dim3 grid((a.ntiles + kWavesPerBlock - 1) / kWavesPerBlock);
+    uint32_t blocks = (a.ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (max_blocks && max_blocks < blocks) blocks = max_blocks;
+    const dim3 grid(blocks);
     if (pair) {
         if (aligned) hipLaunchKernelGGL((k_diff_pack<true, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((k_diff_pack<true, false>), grid, block, 0, s, a);
@@ -484,6 +488,9 @@ __device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint32_
 #ifndef MI355_XROUNDS
 #define MI355_XROUNDS 3
 #endif
+#ifndef MI355_XPRIO
+#define MI355_XPRIO 2
+#endif
 // Ablation builds of the expander (tools/ab_build.sh, never shipped): 1 = prologue only (meta, scans), 2 = + table and
 // code loads, 3 = + record loads, 4 = + staging in LDS but no output stores.  0 = the product.
 #ifndef MI355_XABLATE
@@ -536,6 +543,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     __shared__ uint8_t s_tile[kWTiles * 64];      // candidate of the wave -> its tile
     __shared__ uint2 s_tinfo[kWTiles];            // per tile: {byte offset of its candidate 0 in the code log - 4 * (candidates before the tile), byte offset of its first record}
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[kWStage];   // (byte index relative to the wave's first tile) << 8 | difference
+#if MI355_XPRIO
+    // beside the next batch's pack kernel (pipelined batches) these short, latency-bound waves must not queue for
+    // issue slots behind the older, issue-hungry pack waves
+    __builtin_amdgcn_s_setprio(MI355_XPRIO);
+#endif
     const uint32_t lane = threadIdx.x;
     const uint32_t ngroups = (a.ntiles + kXTiles - 1) / kXTiles;
     const uint32_t t = blockIdx.y, sub = blockIdx.x;

@@ -565,102 +565,80 @@ __global__ __launch_bounds__(256) void k_red_stream(uint8_t *out, size_t stride,
 }
 
 // The cleared form (NOISE_VISUALIZER 2: memset + red_black_map_overlap, kernels.cu:513-514) in ONE pass that only
-// writes: a workgroup owns a slice of kRedSlice bytes (whole pixels) of one frame, finds the frame's entries that
-// fall into it (the indices of a frame are ascending; k_red_bounds has looked the boundaries up), builds the slice
-// in LDS (zeros, 255 in the red byte of every pixel owning an entry) and stores it with 16-byte stores.
-// N bytes written per frame and nothing else (memset + byte scatter was 2.7 us per 1080p frame).  A workgroup
-// writes kRedSlicesPerBlock consecutive slices.
-constexpr uint32_t kRedSlice = 12288;   // 4096 pixels
+// writes: a WAVE owns a slice of kRedSlice = 3 KiB (1024 whole pixels) of one frame, takes the frame's entries that
+// fall into it (the indices of a frame are ascending; k_red_bounds has looked the slice boundaries up), builds the
+// slice in its own 3 KiB of LDS (zeros, 255 in the red byte of every pixel owning an entry) and stores it with three
+// wave-contiguous 1 KiB stores.  N bytes written per frame and nothing else (memset + byte scatter was 2.7 us per
+// 1080p frame; the round-2 form -- 12 KiB slices per workgroup, every slice scanning the entries of eight, three
+// workgroup barriers per slice -- 2.2 us).  No workgroup barrier: a wave's LDS operations execute in order.
+constexpr uint32_t kRedSlice = 3072;   // 1024 pixels
 
-// bounds[t][j] = entries of frame t below byte j * kRedSlice * kRedSlicesPerBlock (j = 0 .. blocks per frame):
-// one thread per boundary, a plain binary search (17 dependent probes at 1080p, all boundaries of all frames at
-// once: ~20 us per launch).  Searching inside k_red_stream_clear instead (256-ary, per workgroup) cost 1.8 us
-// per 1080p frame: 6144 workgroups each paying the probes' latency.
+// bounds[t][j] = entries of frame t below byte j * kRedSlice (j = 0 .. slices per frame): one thread per boundary,
+// a plain binary search (17 dependent probes at 1080p, all boundaries of all frames at once).
 __global__ __launch_bounds__(256) void k_red_bounds(const uint32_t *offsets, const int32_t *xs, uint32_t nbytes,
-                                                    uint32_t per_block, uint32_t nbounds, uint32_t *bounds) {
-    const uint32_t first = offsets[blockIdx.x], n = offsets[blockIdx.x + 1] - first;
-    for (uint32_t j = threadIdx.x; j < nbounds; j += 256) {
-        const uint64_t tgt64 = (uint64_t)j * per_block;
-        const uint32_t target = tgt64 < nbytes ? (uint32_t)tgt64 : nbytes;
-        uint32_t lo = 0, hi = n;                       // lower bound: entries with xs < target
-        while (lo < hi) {
-            const uint32_t mid = lo + (hi - lo) / 2;
-            if ((uint32_t)xs[first + mid] < target) lo = mid + 1;
-            else hi = mid;
-        }
-        bounds[(size_t)blockIdx.x * nbounds + j] = lo;
+                                                    uint32_t nbounds, uint32_t *bounds) {
+    const uint32_t first = offsets[blockIdx.y], n = offsets[blockIdx.y + 1] - first;
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= nbounds) return;
+    const uint64_t tgt64 = (uint64_t)j * kRedSlice;
+    const uint32_t target = tgt64 < nbytes ? (uint32_t)tgt64 : nbytes;
+    uint32_t lo = 0, hi = n;                       // lower bound: entries with xs < target
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if ((uint32_t)xs[first + mid] < target) lo = mid + 1;
+        else hi = mid;
     }
+    bounds[(size_t)blockIdx.y * nbounds + j] = lo;
 }
 
-// workgroup barrier for hand-offs through LDS only: __syncthreads() also waits for the slice stores in flight
-__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-constexpr uint32_t kRedKeep = 2048;          // entries of a workgroup's range kept in LDS
-constexpr uint32_t kRedSlicesPerBlock = 8;   // slices a workgroup writes one after the other: one search for all of them
-
 __global__ __launch_bounds__(256) void k_red_stream_clear(uint8_t *out, size_t stride, const uint32_t *offsets,
-                                                          const int32_t *xs, uint32_t nbytes, const uint32_t *bounds) {
-    __shared__ uint4 s_slice[kRedSlice / 16];
-    const uint32_t first = offsets[blockIdx.y], n = offsets[blockIdx.y + 1] - first;
-    const uint32_t a0 = blockIdx.x * (kRedSlice * kRedSlicesPerBlock);
-    const uint32_t b0 = min(a0 + kRedSlice * kRedSlicesPerBlock, nbytes);
-    (void)n;
-    const uint32_t *bd = bounds + (size_t)blockIdx.y * (gridDim.x + 1u) + blockIdx.x;
+                                                          const int32_t *xs, uint32_t nbytes, const uint32_t *bounds,
+                                                          uint32_t nslices) {
+    __shared__ uint4 s_slice[4][kRedSlice / 16];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t slice = blockIdx.x * 4u + wave;
+    if (slice >= nslices) return;   // wave-uniform
+    const uint32_t first = offsets[blockIdx.y];
+    const uint32_t *bd = bounds + (size_t)blockIdx.y * (nslices + 1u) + slice;
 #if defined(MI355_RED_ABLATE)
     const uint32_t lo = bd[0], hi = lo + (bd[1] & 0u);    // timing builds only: the bare slice writes
 #else
-    const uint32_t lo = bd[0], hi = bd[1];                // the entries of this workgroup's whole range
+    const uint32_t lo = bd[0], hi = bd[1];                // the entries of this slice
 #endif
-    uint8_t *bytes = reinterpret_cast<uint8_t *>(s_slice);
-    // the range's entries come into LDS once (a few hundred on webcam-like input); every slice then looks at all
-    // of them there.  (Re-reading them from global memory for every slice exposed a load latency per slice:
-    // 1.4 us per 1080p frame.)  More than kRedKeep entries (dense frames): read from global memory as needed.
-    __shared__ uint32_t s_ent[kRedKeep];
-    const uint32_t cnt = hi - lo;
-    const bool kept = cnt <= kRedKeep;
-    if (kept)
-        for (uint32_t i = threadIdx.x; i < cnt; i += 256) s_ent[i] = (uint32_t)xs[first + lo + i];
-    for (uint32_t a = a0; a < b0; a += kRedSlice) {
-        const uint32_t b = min(a + kRedSlice, b0);
-        for (uint32_t i = threadIdx.x; i < kRedSlice / 16; i += 256) s_slice[i] = make_uint4(0, 0, 0, 0);
-        lds_only_barrier();
-        // slices are whole pixels: x in [a, b) <=> the painted byte x + (2 - x % 3) in [a, b)  (kernels.cu:273-281)
-        if (kept) {            // workgroup-uniform; two loops so that the LDS form issues no global load at all
-            for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
-                const uint32_t x = s_ent[i];
-                if (x >= a && x < b) bytes[x + (2u - x % 3u) - a] = 255;
-            }
-        } else {
-            for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
-                const uint32_t x = (uint32_t)xs[first + lo + i];
-                if (x >= a && x < b) bytes[x + (2u - x % 3u) - a] = 255;
-            }
-        }
-        lds_only_barrier();
-        uint8_t *img = out + (size_t)blockIdx.y * stride + a;
-        const uint32_t len = b - a;
-        for (uint32_t i = threadIdx.x; i * 16u < len; i += 256) {
-            if (i * 16u + 16u <= len) *reinterpret_cast<uint4 *>(img + i * 16u) = s_slice[i];
-            else for (uint32_t k = i * 16u; k < len; k++) img[k] = bytes[k];
-        }
-        lds_only_barrier();
+    const uint32_t a = slice * kRedSlice, len = min(kRedSlice, nbytes - a);
+    uint4 *sl = s_slice[wave];
+    uint8_t *bytes = reinterpret_cast<uint8_t *>(sl);
+#pragma unroll
+    for (uint32_t j = 0; j < 3; j++) sl[j * 64u + lane] = make_uint4(0, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // slices are whole pixels: x in [a, a + len) <=> the painted byte x + (2 - x % 3) in it  (kernels.cu:273-281)
+    for (uint32_t i = lo + lane; i < hi; i += 64u) {
+        const uint32_t x = (uint32_t)xs[first + i] - a;
+        bytes[x + (2u - x % 3u)] = 255;                    // a is a multiple of 3: (x - a) % 3 == x % 3
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint8_t *img = out + (size_t)blockIdx.y * stride + a;
+#pragma unroll
+    for (uint32_t j = 0; j < 3; j++) {
+        const uint32_t o = (j * 64u + lane) * 16u;
+        if (o + 16u <= len) *reinterpret_cast<uint4 *>(img + o) = sl[j * 64u + lane];
+        else for (uint32_t k = o; k < len; k++) img[k] = bytes[k];
     }
 }
 
-uint32_t red_bounds_per_frame(uint32_t nbytes) {
-    const uint32_t per_block = kRedSlice * kRedSlicesPerBlock;
-    return (nbytes + per_block - 1) / per_block + 1u;
-}
+uint32_t red_bounds_per_frame(uint32_t nbytes) { return (nbytes + kRedSlice - 1) / kRedSlice + 1u; }
 
 hipError_t launch_red_stream(uint8_t *out, const uint32_t *offsets, const int32_t *xs, uint32_t nbytes, bool clear,
                              FrameBatch fb, hipStream_t s, uint32_t *bounds_scratch) {
     if (fb.nframes <= 0 || nbytes == 0) return hipSuccess;
     if (clear && bounds_scratch && aligned16(out) && fb.stride % 16 == 0) {
-        const uint32_t per_block = kRedSlice * kRedSlicesPerBlock, nb = red_bounds_per_frame(nbytes);
-        hipLaunchKernelGGL(k_red_bounds, dim3((unsigned)fb.nframes), dim3(256), 0, s, offsets, xs, nbytes, per_block, nb,
-                           bounds_scratch);
-        hipLaunchKernelGGL(k_red_stream_clear, dim3(nb - 1u, (unsigned)fb.nframes), dim3(256), 0, s, out, fb.stride,
-                           offsets, xs, nbytes, bounds_scratch);
+        const uint32_t nb = red_bounds_per_frame(nbytes), nslices = nb - 1u;
+        hipLaunchKernelGGL(k_red_bounds, dim3((nb + 255u) / 256u, (unsigned)fb.nframes), dim3(256), 0, s, offsets, xs, nbytes,
+                           nb, bounds_scratch);
+        hipLaunchKernelGGL(k_red_stream_clear, dim3((nslices + 3u) / 4u, (unsigned)fb.nframes), dim3(256), 0, s, out,
+                           fb.stride, offsets, xs, nbytes, bounds_scratch, nslices);
         return hipGetLastError();
     }
     if (clear) {

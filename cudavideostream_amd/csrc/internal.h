@@ -103,11 +103,11 @@ hipError_t launch_diff_chain(const ChainArgs &a, uint32_t resident_workgroups, h
 struct mi355_core;
 namespace mi355 {
 int set_error(int code, const char *what);        // sets the calling thread's mi355_last_error text, returns code
-hipStream_t core_stream(const ::mi355_core *c);   // the stream the core currently enqueues on
+hipStream_t core_stream(::mi355_core *c);   // the stream the core currently enqueues on (joins a pipelined batch's side stream first)
 int core_device(const ::mi355_core *c);
 
 // diff_pack.hip
-hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, hipStream_t s);
+hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, uint32_t max_blocks /* 0: one tile per wave */, hipStream_t s);
 uint32_t expand_groups(uint32_t ntiles);
 hipError_t launch_scan(const uint4 *meta, uint32_t *roff, uint32_t *totals, uint32_t ntiles,
                        int nframes, uint32_t *offsets, uint32_t *ticket /* zero between launches */,

@@ -169,7 +169,11 @@ int mi355_red_overlap(mi355_core *core, void *d_img, const void *d_xs, const voi
                       uint32_t count);
 /* The same from a packed stream, for a batch: frame t (at d_frames + t*stride_bytes) gets R = 255 for every
  * pixel owning one of its entries xs[offsets[t] .. offsets[t+1]).  clear != 0 zeroes the frames first
- * (NOISE_VISUALIZER 2, kernels.cu:513); clear == 0 paints onto what they hold (NOISE_VISUALIZER 3, :517). */
+ * (NOISE_VISUALIZER 2, kernels.cu:513); clear == 0 paints onto what they hold (NOISE_VISUALIZER 3, :517).
+ * clear != 0 builds every frame from its entries in ONE write-only pass and needs them ASCENDING within the
+ * frame -- as every diff entry point of this library produces them (the pass finds a slice's entries by
+ * binary search; entries out of order would be dropped without an error) -- and nframes <= max_batch.
+ * clear == 0 is a plain scatter: any order, any nframes. */
 int mi355_red_stream_batch(mi355_core *core, const void *d_offsets, const void *d_xs, int nframes,
                            void *d_frames, size_t stride_bytes, int clear);
 /* kernels.cu:97-136: 3x3 convolution with the kernel of mi355_set_conv_kernel; not in-place.  fp32, taps in

@@ -358,3 +358,76 @@ def test_heavy_record_count_per_wave(po, heavy):
         assert g_off.tolist() == [0, c]
         assert np.array_equal(g_xs, xs) and np.array_equal(g_df, df)
         assert np.array_equal(core.get_state(), st)
+
+
+# ---- pipelined batches: expansion of batch k beside the pack kernel of batch k + 1 (own stream) ---------------------------
+def test_back_to_back_batches_without_synchronisation(po):
+    """Seven batches of one stream queued back to back on the core's own stream (the index and the expansion of a
+    batch then run on the side stream beside the next batch's pack kernel, two sets of logs in turn), every batch
+    into its own output buffers; one synchronisation at the end; every batch against the oracle, state carried."""
+    w, h, T, K = 320, 180, 6, 7
+    n = 3 * w * h
+    base, frames = synth.webcam_stream(T * K, w, h, seed=33)
+    eo, exs, edf, est = po.diff_stream(frames, base)
+    d_fr = to_dev(frames)
+    outs = [(torch.zeros(T + 1, dtype=torch.int32, device=DEV), torch.full((T * n,), -7, dtype=torch.int32, device=DEV),
+             torch.zeros(T * n, dtype=torch.uint8, device=DEV)) for _ in range(K)]
+    with CUDACore(w, h, max_batch=T, sample_mat_data=base) as core:
+        torch.cuda.synchronize()
+        bound = object.__getattribute__(core, "diff_stream_batch")   # no host synchronisation between the calls
+        for k in range(K):
+            bound(d_fr[k * T:(k + 1) * T], T, *outs[k], T * n)
+        core.synchronize()
+        assert np.array_equal(core.get_state(), est)
+    # oracle: per-frame entries of the whole sequence, cut into the batches
+    per_frame = np.diff(eo.astype(np.int64))
+    at = 0
+    for k in range(K):
+        cnt = per_frame[k * T:(k + 1) * T]
+        off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint32)
+        tot = int(off[-1])
+        assert np.array_equal(outs[k][0].cpu().numpy().view(np.uint32), off), k
+        assert np.array_equal(outs[k][1][:tot].cpu().numpy(), exs[at:at + tot]), k
+        assert np.array_equal(outs[k][2][:tot].cpu().numpy(), edf[at:at + tot]), k
+        at += tot
+
+
+def test_pipelined_batches_then_other_entry_points(po):
+    """What follows a pipelined batch on the same core -- here the red motion map built from the batch's packed
+    stream, queued at once -- sees the batch complete (every entry point joins the side stream first); the client's
+    reconstruction on a second core after one synchronisation of the server."""
+    w, h, T = 256, 144, 5
+    n = 3 * w * h
+    base, frames = synth.webcam_stream(3 * T, w, h, seed=34)
+    eo, exs, edf, est = po.diff_stream(frames, base)
+    per_frame = np.diff(eo.astype(np.int64))
+    d_fr = to_dev(frames)
+    with CUDACore(w, h, max_batch=T, sample_mat_data=base) as core, CUDACore(w, h, max_batch=T, sample_mat_data=base) as client:
+        torch.cuda.synchronize()
+        stream_batch = object.__getattribute__(core, "diff_stream_batch")
+        red_batch = object.__getattribute__(core, "red_stream_batch")
+        outs, maps = [], []
+        for k in range(3):
+            d_off = torch.zeros(T + 1, dtype=torch.int32, device=DEV)
+            d_xs = torch.zeros(T * n, dtype=torch.int32, device=DEV)
+            d_df = torch.zeros(T * n, dtype=torch.uint8, device=DEV)
+            d_map = torch.full((T, n), 0x5a, dtype=torch.uint8, device=DEV)
+            torch.cuda.synchronize()
+            stream_batch(d_fr[k * T:(k + 1) * T], T, d_off, d_xs, d_df, T * n)
+            red_batch(d_off, d_xs, T, d_map, True)             # reads the batch's output at once
+            outs.append((d_off, d_xs, d_df)); maps.append(d_map)
+        core.synchronize()
+        at = 0
+        for k in range(3):
+            got = maps[k].cpu().numpy()
+            for t in range(T):
+                cnt = int(per_frame[k * T + t])
+                want = np.zeros(n, np.uint8)
+                x = exs[at:at + cnt].astype(np.int64)
+                want[x + (2 - x % 3)] = 255                     # kernels.cu:273-281 on a cleared frame
+                assert np.array_equal(got[t], want), (k, t)
+                at += cnt
+            client.apply_batch(*outs[k], T)
+        client.synchronize()
+        assert np.array_equal(client.get_state(), est)          # the client's frame == the server's state
+        assert np.array_equal(core.get_state(), est)

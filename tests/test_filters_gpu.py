@@ -1,6 +1,8 @@
 """GPU parity of the filter kernels (gray, binarize chain, heat map, red map, 3x3 noise filter) and of
 the per-frame host entry point exec_core, bit-exact against the CPU oracle and the fixtures recorded
 from the reference's own server.cpp CPU branch."""
+import os
+
 import numpy as np
 import pytest
 
@@ -494,3 +496,70 @@ def test_config3_and_config4_at_1080p(po):
                 assert np.array_equal(n_frame.array[:n], show)
             for a in (h_frame, n_frame, o_frame, h_xs):
                 a.free()
+
+
+# ---- pins that do not pass through the oracle of the same box ------------------------------------------------------------
+def test_fused_binarize_vs_reference_run_at_1080p():
+    """The fused avg-gray + binarize chain at BASELINE size against a recorded run of the reference's own server.cpp
+    CPU branch (tests/golden/ref_server_cpu_1080p.npz: SHA-256 of the outputs, white bytes; interior threshold and
+    both clamps)."""
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_ref_1080p import H, SEED, T, W
+    g = golden("ref_server_cpu_1080p.npz")
+    fr = torch.stack([synth.webcam_frame(t, W, H, seed=SEED, device=DEV) for t in range(T)])
+    fr[1] = fr[1] // 6
+    fr[2] = 200 + fr[2] // 5
+    with CUDACore(W, H, max_batch=T) as core:
+        d_o = torch.zeros_like(fr)
+        core.filter_batch(lib.OP_GRAY_AVG_BINARIZE, fr, d_o, T)
+        core.synchronize()
+        out = d_o.cpu().numpy()
+    for t in range(T):
+        assert hashlib.sha256(out[t].tobytes()).digest() == bytes(g["sha256"][t]), f"frame {t}"
+        assert int((out[t] == 255).sum()) == int(g["white"][t])
+
+
+def test_heat_map_against_the_committed_lut_every_distance():
+    """Every d = |dB| + |dG| + |dR| in 0..765 on the device against the COMMITTED 766 x 3 table
+    (tests/golden/oracle_heat_lut.npz), not against an oracle evaluated with this box's libm: the table the library
+    builds at mi355_create with the host's sin() is what is being checked."""
+    lut = golden("oracle_heat_lut.npz")["lut"].reshape(766, 3)
+    ds = np.arange(766)
+    # a pixel pair for every d: differences spread over the three channels, both signs
+    db, dg = np.minimum(ds, 255), np.minimum(np.maximum(ds - 255, 0), 255)
+    dr = ds - db - dg
+    npix = 768
+    cur = np.zeros((npix, 3), np.uint8)
+    prev = np.zeros((npix, 3), np.uint8)
+    cur[:766, 0], prev[:766, 1], cur[:766, 2] = db, dg, dr      # |cur - prev| per channel: dB, dG, dR
+    with CUDACore(npix, 1) as core:
+        d_o = dev_out(3 * npix)
+        core.heat_map(to_dev(cur.reshape(-1)), to_dev(prev.reshape(-1)), d_o)
+        core.synchronize()
+        out = d_o.cpu().numpy().reshape(-1, 3)
+    assert np.array_equal(out[:766], lut), np.nonzero((out[:766] != lut).any(axis=1))[0][:10]
+
+
+def test_batch_filters_against_the_committed_64x48_fixture():
+    """Every filter of mi355_filter_batch on the committed inputs of tests/golden/oracle_filters_64x48.npz against the
+    committed outputs (made in the build container), through the batch entry point."""
+    g = golden("oracle_filters_64x48.npz")
+    w, h = int(g["width"]), int(g["height"])
+    T = 3
+    img = np.repeat(g["img"][None, :], T, axis=0)
+    prv = np.repeat(g["prev"][None, :], T, axis=0)
+    with CUDACore(w, h, k=g["k"], max_batch=T) as core:
+        for op, two, key in ((lib.OP_GRAY_AVG, False, "gray_avg"), (lib.OP_GRAY_WEIGHTED, False, "gray_weighted"),
+                             (lib.OP_GRAY_WEIGHTED_BINARIZE, False, "binarized"), (lib.OP_HEAT_MAP, True, "heat"),
+                             (lib.OP_RED_DENSE, True, "red"), (lib.OP_CONV3X3, False, "conv")):
+            d_o = torch.zeros_like(to_dev(img))
+            if two:
+                core.filter_batch(op, to_dev(img), d_o, T, d_in2=to_dev(prv))
+            else:
+                core.filter_batch(op, to_dev(img), d_o, T)
+            core.synchronize()
+            out = d_o.cpu().numpy()
+            for t in range(T):
+                assert np.array_equal(out[t], g[key]), (key, t)

@@ -1,6 +1,7 @@
 """CPU tests of the oracle itself: pinned against the reference's own outputs and identities
  and against the committed golden vectors."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -377,3 +378,20 @@ def test_median5x5_restatement(po):
     assert const[4, 4, 0] == 77          # interior: 25 equal values
     assert const[0, 0, 0] == 0           # corner: 9 image values, 16 zeros -> the 13th smallest is a zero
     assert const[0, 4, 1] == 77          # top edge: 15 image values, 10 zeros
+
+
+def test_cpu_branch_matches_reference_run_at_1080p(po):
+    """The restated CPU branch against a recorded run of the reference's own server.cpp at BASELINE size (digests;
+    tests/golden/make_ref_1080p.py regenerates the seeded inputs)."""
+    import hashlib
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_ref_1080p import frames_1080p
+    g = golden("ref_server_cpu_1080p.npz")
+    _, fr = frames_1080p()
+    assert fr.shape[0] == int(g["nframes"])
+    for t in range(fr.shape[0]):
+        out, thr = po.server_cpu_branch(fr[t])[:2]
+        assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).digest() == bytes(g["sha256"][t]), f"frame {t}"
+        assert int((out == 255).sum()) == int(g["white"][t])
+        if int(g["thr"][t]) >= 0:
+            assert int(thr) == int(g["thr"][t])
