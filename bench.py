@@ -572,7 +572,9 @@ def pair_mode(args, core, frames, d_off, d_xs, d_df, cap, n):
     than in the stream.)"""
     B = frames.shape[0] // 2
     cur, prev = frames[:B], frames[B:2 * B]
+    core.use_torch_stream()   # one batch after the other (a caller's stream is never pipelined): the kernels' own times add up
     sec, ms, launches = timed_path(core, lambda: core.diff_pairs_batch(cur, prev, B, d_off, d_xs, d_df, cap), 20)
+    core.use_own_stream()
     p = int(d_off.cpu().numpy().view(np.uint32)[B])
     return path_line(B, n, p, sec, ms, launches, True)
 

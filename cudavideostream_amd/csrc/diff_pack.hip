@@ -339,6 +339,10 @@ __global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t
                                                      uint32_t ntiles, uint32_t ngroups, uint32_t *ticket,
                                                      uint32_t *offsets) {
     static_assert(kXTiles == 64, "one wave reduces one group");
+#if MI355_XPRIO
+    __builtin_amdgcn_s_setprio(3);   // pipelined batches: this short kernel gates the expansion; it must not queue for
+                                     // issue slots behind the next batch's pack waves
+#endif
     __shared__ uint32_t s_sum[kScanChunk];
     __shared__ uint32_t s_part[kScanChunk][3];
     __shared__ uint32_t s_scan[5];
