@@ -768,28 +768,28 @@ int mi355_merge_parts(mi355_core *c, int nparts, int nframes, const void *d_part
 
 int mi355_int_diff(mi355_core *c, const void *d_cur, const void *d_prev, void *d_out, size_t n) {
     if (!c || (n && (!d_cur || !d_prev || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
-    if (int rc = use_device(c)) return rc;
+    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
     HIP_TRY(launch_int_diff((const int32_t *)d_cur, (const int32_t *)d_prev, (int32_t *)d_out, n, c->stream));
     return MI355_OK;
 }
 
 int mi355_gray_avg(mi355_core *c, const void *d_in, void *d_out) {
     if (!c || (c->n && (!d_in || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
-    if (int rc = use_device(c)) return rc;
+    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
     HIP_TRY(launch_gray((const uint8_t *)d_in, (uint8_t *)d_out, c->n / 3, false, FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
 }
 
 int mi355_gray_weighted(mi355_core *c, const void *d_in, void *d_out) {
     if (!c || (c->n && (!d_in || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
-    if (int rc = use_device(c)) return rc;
+    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
     HIP_TRY(launch_gray((const uint8_t *)d_in, (uint8_t *)d_out, c->n / 3, true, FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
 }
 
 int mi355_binarize_chain(mi355_core *c, const void *d_gray, void *d_out, void *d_hist, void *d_thr) {
     if (!c || (c->n && (!d_gray || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
-    if (int rc = use_device(c)) return rc;
+    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
     int32_t *hist = d_hist ? (int32_t *)d_hist : c->hist;
     int32_t *thr = d_thr ? (int32_t *)d_thr : c->thr;
     HIP_TRY(launch_binarize_chain((const uint8_t *)d_gray, (uint8_t *)d_out, c->n, hist, thr, FrameBatch{c->n, 1}, c->stream));
@@ -798,7 +798,7 @@ int mi355_binarize_chain(mi355_core *c, const void *d_gray, void *d_out, void *d
 
 int mi355_heat_map(mi355_core *c, const void *d_cur, const void *d_prev, void *d_out) {
     if (!c || (c->n && (!d_cur || !d_prev || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
-    if (int rc = use_device(c)) return rc;
+    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
     HIP_TRY(launch_heat_map((const uint8_t *)d_cur, (const uint8_t *)d_prev, (uint8_t *)d_out, c->n / 3,
                             c->lut, FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
@@ -806,7 +806,7 @@ int mi355_heat_map(mi355_core *c, const void *d_cur, const void *d_prev, void *d
 
 int mi355_red_dense(mi355_core *c, const void *d_cur, const void *d_prev, void *d_out) {
     if (!c || (c->n && (!d_cur || !d_prev || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
-    if (int rc = use_device(c)) return rc;
+    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
     HIP_TRY(launch_red_dense((const uint8_t *)d_cur, (const uint8_t *)d_prev, (uint8_t *)d_out, c->n / 3,
                              c->cfg.threshold, FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
@@ -841,7 +841,7 @@ int mi355_conv3x3(mi355_core *c, const void *d_in, void *d_out) {
     if (!c || (c->n && (!d_in || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
     if (d_in == d_out && c->n) return fail(MI355_ERR_INVALID, "conv3x3 cannot run in place");
     if (!c->have_k9) return fail(MI355_ERR_STATE, "mi355_set_conv_kernel not called");
-    if (int rc = use_device(c)) return rc;
+    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
     HIP_TRY(launch_conv3x3((const uint8_t *)d_in, (uint8_t *)d_out, c->cfg.width, c->cfg.height, c->k9,
                            c->k9_sym, FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
@@ -851,7 +851,7 @@ int mi355_conv_kxk(mi355_core *c, const void *d_in, void *d_out, const float *k,
     if (!c || !k || (c->n && (!d_in || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
     if (K < 1 || K > 9) return fail(MI355_ERR_INVALID, "K outside [1, 9]");
     if (d_in == d_out && c->n) return fail(MI355_ERR_INVALID, "conv_kxk cannot run in place");
-    if (int rc = use_device(c)) return rc;
+    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
     if (!c->kxk)
         if (int rc = dev_alloc(c, &c->kxk, 81)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));    // a filter of an earlier call may still be reading the taps
@@ -865,7 +865,7 @@ int mi355_conv_kxk(mi355_core *c, const void *d_in, void *d_out, const float *k,
 int mi355_median5x5(mi355_core *c, const void *d_in, void *d_out) {
     if (!c || !d_in || !d_out) return fail(MI355_ERR_INVALID, "null argument");
     if (d_in == d_out) return fail(MI355_ERR_INVALID, "median is not in-place");
-    if (int rc = use_device(c)) return rc;
+    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
     HIP_TRY(launch_median5x5((const uint8_t *)d_in, (uint8_t *)d_out, c->cfg.width, c->cfg.height,
                              FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
@@ -883,7 +883,7 @@ int mi355_filter_batch(mi355_core *c, int op, const void *d_in, const void *d_in
     if (op == MI355_OP_CONV3X3 && !c->have_k9) return fail(MI355_ERR_STATE, "mi355_set_conv_kernel not called");
     if ((op == MI355_OP_CONV3X3 || op == MI355_OP_MEDIAN5X5) && d_in == d_out)
         return fail(MI355_ERR_INVALID, "neighbourhood filters cannot run in place");
-    if (int rc = use_device(c)) return rc;
+    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
     const uint8_t *in = (const uint8_t *)d_in, *in2 = (const uint8_t *)d_in2;
     uint8_t *out = (uint8_t *)d_out;
     const FrameBatch fb{stride_bytes, nframes};

@@ -104,7 +104,16 @@ int mi355_set_glyphs(mi355_core *core, const uint8_t *chars_px, int nglyphs, int
  *   d_xs     : int32[capacity]  byte indices, frame t's entries at [offsets[t], offsets[t+1])
  *   d_diff   : uint8[capacity]  (uint8)df of the same entries
  * Entries beyond `capacity` are dropped (offsets stay exact), so check offsets[nframes] <= capacity.
- * Asynchronous on the core's stream. */
+ * Asynchronous.  On the core's OWN stream consecutive batches are pipelined: the index and the expansion of a
+ * batch run on a side stream beside the next batch's pack kernel.  A batch's outputs (d_offsets, d_xs, d_diff,
+ * d_wire) are complete after mi355_synchronize and for every later call on this core that can consume them
+ * (mi355_apply_*, mi355_red_stream_batch / _red_overlap, mi355_merge_parts, mi355_download, mi355_exec /
+ * mi355_pipe_*, the group gather) -- these first wait for the last expansion.  The frame filters (mi355_filter_batch,
+ * mi355_gray_*, mi355_binarize_chain, mi355_heat_map, mi355_red_dense, mi355_conv*, mi355_median5x5,
+ * mi355_int_diff) take frames, not packed streams, and are ordered on the core's stream only: they may run beside
+ * the expansion of the batch before (visualiser of frame k + 1 beside the expansion of frame k).  With a caller's
+ * stream (mi355_set_stream) nothing is pipelined: every kernel runs on that stream, in call order.
+ * MI355_PIPELINE=0 in the environment switches the pipelining off. */
 int mi355_diff_stream_batch(mi355_core *core, const void *d_frames, size_t stride_bytes, int nframes,
                             void *d_offsets, void *d_xs, void *d_diff, size_t capacity);
 
