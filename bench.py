@@ -454,6 +454,8 @@ def main():
         if world == 1 and not args.no_pair and not rr:
             out["pair_mode"] = pair_mode(args, core, frames, d_off, d_xs, d_df, cap, n)
             out["regimes"] = regimes(args, dev)
+        if world == 1 and not args.no_pair and not rr:
+            out["two_streams_one_gpu"] = two_streams(args, core, frames, base, d_off, d_xs, d_df, cap, dev)
         if world == 1 and not args.no_filters and not rr:
             out.update(filter_configs(args, dev))
         if world == 1 and not args.no_host_path:
@@ -577,6 +579,40 @@ def pair_mode(args, core, frames, d_off, d_xs, d_df, cap, n):
     core.use_own_stream()
     p = int(d_off.cpu().numpy().view(np.uint32)[B])
     return path_line(B, n, p, sec, ms, launches, True)
+
+
+def two_streams(args, core, frames, base, d_off, d_xs, d_df, cap, dev, reps=20):
+    """Secondary line, NOT the bench's workload: two independent streams of the same shape on the one GPU, each on its
+    own core and stream.  Their kernels overlap in every combination, which a single stream's batches cannot (the
+    pack kernel of batch k + 1 needs the state of batch k): the aggregate shows how far instruction issue, not the
+    memory system, is from being saturated by one stream."""
+    B = frames.shape[0]
+    try:
+        base2, frames2 = synth.webcam_stream(B, args.width, args.height, seed=121, device=dev)
+        o2 = (torch.zeros_like(d_off), torch.empty_like(d_xs), torch.empty_like(d_df))
+        with CUDACore(args.width, args.height, max_batch=B) as core2:
+            core2.set_state(base2.cpu().numpy())
+            torch.cuda.synchronize()
+
+            def both():
+                core.diff_stream_batch(frames, B, d_off, d_xs, d_df, cap)
+                core2.diff_stream_batch(frames2, B, *o2, cap)
+
+            for _ in range(3):
+                both()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                both()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            p = int(d_off.cpu().numpy().view(np.uint32)[B]) + int(o2[0].cpu().numpy().view(np.uint32)[B])
+        alg = 2.0 * frames.shape[1] * 2 * B + 5.0 * p
+        return {"frames_per_s": round(2 * B / dt, 1), "ms_per_round_of_two_batches": round(dt * 1e3, 4),
+                "frac": round(alg / dt / 1e9 / HBM_PEAK_GBPS, 4),
+                "note": "two cores, two streams, 2 x %d frames per round; wall clock" % B}
+    except Exception as e:   # noqa: BLE001  -- a secondary line must not cost the bench line (memory on a shared box)
+        return {"skipped": repr(e)[:160]}
 
 
 def regimes(args, dev, B=32):

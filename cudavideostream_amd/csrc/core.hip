@@ -499,7 +499,12 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (!cfg || !out) return fail(MI355_ERR_INVALID, "null argument");
     *out = nullptr;
     if (cfg->width < 0 || cfg->height < 0) return fail(MI355_ERR_INVALID, "negative frame size");
-    if (cfg->threshold < 0 || cfg->threshold > 127) return fail(MI355_ERR_INVALID, "threshold outside 0..127");
+    // |df| of two bytes is at most 255: a threshold of 255 flags nothing; larger or negative values are refused
+    if (cfg->threshold < 0 || cfg->threshold > 255) return fail(MI355_ERR_INVALID, "threshold outside 0..255");
+#if MI355_EXPERIMENTS
+    if (cfg->threshold > 127 && (cfg->flags & (MI355_FLAG_FUSED | MI355_FLAG_CHAIN)))
+        return fail(MI355_ERR_INVALID, "the experiment kernels take thresholds 0..127");
+#endif
     if (cfg->max_batch < 1) return fail(MI355_ERR_INVALID, "max_batch < 1");
     if (cfg->visualizer < 0 || cfg->visualizer > 5) return fail(MI355_ERR_INVALID, "unknown visualizer");
     const uint64_t n64 = 3ull * (uint64_t)cfg->width * (uint64_t)cfg->height;

@@ -76,6 +76,7 @@ struct LogOut {
 
 // One frame of one tile, arithmetic only: compare, feed back.  dm = the 16 masked difference bytes,
 // m16 = map of the flagged bytes.
+template <bool HIGH>
 __device__ __forceinline__ void compare_step(const uint4 c, uint4 &s, ThrConst tc, uint32_t (&dm)[4], uint32_t &m16) {
     const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
     uint32_t sw[4] = {s.x, s.y, s.z, s.w};
@@ -86,7 +87,7 @@ __device__ __forceinline__ void compare_step(const uint4 c, uint4 &s, ThrConst t
         sw[k] ^= cw[k]; dm[k] = 0; fh[k] = 0;
 #else
         uint32_t x;
-        fh[k] = dword_flags(cw[k], sw[k], tc, x);
+        fh[k] = dword_flags<HIGH>(cw[k], sw[k], tc, x);
         // 0xFF in every flagged byte: a v_perm selector byte of 0x80 yields the constant 0xFF, one of 0x00
         // byte 0 of the second operand (0)
         const uint32_t mask = __builtin_amdgcn_perm(0u, 0u, fh[k]);
@@ -171,7 +172,7 @@ struct Group {
     }
 };
 
-template <bool PAIR, bool FAST>
+template <bool PAIR, bool FAST, bool HIGH>
 __device__ __forceinline__ void pack_group(const PackArgs &a, const Group<PAIR, FAST> &g, int t0, uint4 &st,
                                            LogPos &lp, uint32_t tile, ThrConst tc, int lane, const LogOut &lg) {
     // The group's kPrefetch meta words are assembled in lanes 0..kPrefetch-1 and leave with ONE store.
@@ -185,13 +186,13 @@ __device__ __forceinline__ void pack_group(const PackArgs &a, const Group<PAIR, 
         const bool two = t + 1 < a.nframes;
         uint32_t dm0[4], m0, m1 = 0, pc0, pm0, pc1 = 0, pm1 = 0;
         if (PAIR) st = g.p[d];
-        compare_step(g.c[d], st, tc, dm0, m0);
+        compare_step<HIGH>(g.c[d], st, tc, dm0, m0);
         const uint32_t c0 = emit_step(dm0, m0, lg, lp, jump, lane24, pc0, pm0);
         uint32_t c1 = 0;
         if (two) {
             if (PAIR) st = g.p[d + 1];
             uint32_t dm1[4];
-            compare_step(g.c[d + 1], st, tc, dm1, m1);
+            compare_step<HIGH>(g.c[d + 1], st, tc, dm1, m1);
             c1 = emit_step(dm1, m1, lg, lp, jump, lane24, pc1, pm1);
         }
         // flagged bytes of the two frames: one register (16-bit fields, a tile holds at most 1024) and one
@@ -215,11 +216,11 @@ __device__ __forceinline__ void pack_group(const PackArgs &a, const Group<PAIR, 
 #endif
 }
 
-template <bool PAIR, bool FAST>
+template <bool PAIR, bool FAST, bool HIGH>
 __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint32_t byte_off,
                                           int valid, int lane) {
     const int T = a.nframes;
-    const ThrConst tc{(127u - (uint32_t)a.thr) * 0x01010101u, (uint32_t)a.thr * 0x01010101u};
+    const ThrConst tc = make_thr((uint32_t)a.thr);
     const LogOut lg{make_rsrc(a.codes, a.codes_bytes), make_rsrc(a.rec, a.rec_bytes), make_rsrc(a.meta, a.meta_bytes)};
 
     uint4 st = make_uint4(0, 0, 0, 0);
@@ -236,12 +237,12 @@ __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint
     for (int t0 = 0;;) {
         cp += gstep; if (PAIR) pp += gstep;
         gb.load(a, byte_off, t0 + kPrefetch, valid, cp, pp, cur_last, prev_last);
-        pack_group<PAIR, FAST>(a, ga, t0, st, lp, tile, tc, lane, lg);
+        pack_group<PAIR, FAST, HIGH>(a, ga, t0, st, lp, tile, tc, lane, lg);
         t0 += kPrefetch;
         if (t0 >= T) break;
         cp += gstep; if (PAIR) pp += gstep;
         ga.load(a, byte_off, t0 + kPrefetch, valid, cp, pp, cur_last, prev_last);
-        pack_group<PAIR, FAST>(a, gb, t0, st, lp, tile, tc, lane, lg);
+        pack_group<PAIR, FAST, HIGH>(a, gb, t0, st, lp, tile, tc, lane, lg);
         t0 += kPrefetch;
         if (t0 >= T) break;
     }
@@ -252,7 +253,7 @@ __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint
     }
 }
 
-template <bool PAIR, bool ALIGNED>
+template <bool PAIR, bool ALIGNED, bool HIGH>
 __global__ __launch_bounds__(256) void k_diff_pack(const PackArgs a) {
     const int lane = threadIdx.x & 63;
     // one tile per wave when the grid covers the frame (the default); a smaller grid walks the tiles with its stride
@@ -262,10 +263,10 @@ __global__ __launch_bounds__(256) void k_diff_pack(const PackArgs a) {
         const uint32_t byte_off = tile_off + (uint32_t)lane * 16u;
         // wave-uniform choice: every lane of a full, aligned tile takes the vector path
         if (ALIGNED && tile_off + kTileBytes <= a.n) {
-            pack_tile<PAIR, true>(a, tile, byte_off, 16, lane);
+            pack_tile<PAIR, true, HIGH>(a, tile, byte_off, 16, lane);
         } else {
             const int valid = byte_off < a.n ? (int)min(16u, a.n - byte_off) : 0;
-            pack_tile<PAIR, false>(a, tile, byte_off, valid, lane);
+            pack_tile<PAIR, false, HIGH>(a, tile, byte_off, valid, lane);
         }
     }
 }
@@ -275,13 +276,22 @@ hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, uint32_t
     uint32_t blocks = (a.ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
     if (max_blocks && max_blocks < blocks) blocks = max_blocks;
     const dim3 grid(blocks);
+    // thresholds of 128 and more (the reference's LR_THRESHOLDS is an unconstrained int, common.h:14) take the HIGH
+    // form of the compare: another instantiation, the same instruction count
+    const bool high = a.thr >= 128;
+#define MI355_LAUNCH_PACK(P, A)                                                                        \
+    do {                                                                                               \
+        if (high) hipLaunchKernelGGL((k_diff_pack<P, A, true>), grid, block, 0, s, a);                 \
+        else hipLaunchKernelGGL((k_diff_pack<P, A, false>), grid, block, 0, s, a);                     \
+    } while (0)
     if (pair) {
-        if (aligned) hipLaunchKernelGGL((k_diff_pack<true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_diff_pack<true, false>), grid, block, 0, s, a);
+        if (aligned) MI355_LAUNCH_PACK(true, true);
+        else MI355_LAUNCH_PACK(true, false);
     } else {
-        if (aligned) hipLaunchKernelGGL((k_diff_pack<false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_diff_pack<false, false>), grid, block, 0, s, a);
+        if (aligned) MI355_LAUNCH_PACK(false, true);
+        else MI355_LAUNCH_PACK(false, false);
     }
+#undef MI355_LAUNCH_PACK
     return hipGetLastError();
 }
 
@@ -544,7 +554,7 @@ __device__ __forceinline__ int row_inclusive_scan(int v) {
 // kernel is a chain of short dependent steps, what hides them is the number of waves.
 template <bool WIRE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_expand(const ExpandArgs a) {
-    __shared__ uint8_t s_tile[kWTiles * 64];      // candidate of the wave -> its tile
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[kWTiles * 64];   // candidate rank of the wave -> tile + 1 at the first candidate of every tile, 0 elsewhere
     __shared__ uint2 s_tinfo[kWTiles];            // per tile: {byte offset of its candidate 0 in the code log - 4 * (candidates before the tile), byte offset of its first record}
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[kWStage];   // (byte index relative to the wave's first tile) << 8 | difference
 #if MI355_XPRIO
@@ -585,14 +595,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             if (dst0 == 0xfffffff0u) a.out_xs[0] = (int32_t)nrec;
 #else
             if (lane < kWTiles) s_tinfo[lane] = make_uint2(m.x - 4u * rexcl, m.y);
-            // which tile candidate r of the wave belongs to: tile i owns ranks rexcl_i .. rexcl_i + nc_i - 1
-#pragma unroll 4
-            for (uint32_t i = 0; i < kWTiles; i++) {
-                const uint32_t nci = (uint32_t)__builtin_amdgcn_readlane((int)nc, (int)i);
-                const uint32_t rx = (uint32_t)__builtin_amdgcn_readlane((int)rexcl, (int)i);
-                if (lane < nci) s_tile[rx + lane] = (uint8_t)i;
-            }
+            // which tile candidate r of the wave belongs to: tile i owns ranks rexcl_i .. rexcl_i + nc_i - 1.  Only the
+            // HEAD of every tile's range is marked (tile + 1 at rank rexcl_i, zeros elsewhere); a running maximum over
+            // the candidates of a round (one DPP scan, the maximum so far carried from round to round) turns the heads
+            // into "my tile" -- instead of a loop over the 16 tiles writing every rank
+            reinterpret_cast<uint4 *>(s_tile)[lane] = make_uint4(0, 0, 0, 0);
+            lds_handoff();
+            if (lane < kWTiles && nc != 0u) s_tile[rexcl] = (uint8_t)(lane + 1u);
             lds_handoff();   // the tables are read by other lanes than the ones that wrote them
+            uint32_t tile_carry = 0;   // highest head seen in the rounds before (wave-uniform)
             const uint32_t xs_base = tile0 * kTileBytes;
             uint32_t carry = 0, flushed = 0;   // entries emitted / already stored
             for (uint32_t base = 0; base < nrec; base += 64u * kXRounds) {
@@ -605,6 +616,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     for (int k = 0; k < kXRounds; k++) {
                         rr[k] = min(base + 64u * (uint32_t)k + lane, nrec - 1u);
                         ti[k] = s_tile[rr[k]];
+                    }
+#pragma unroll
+                    for (int k = 0; k < kXRounds; k++) {
+                        const uint32_t run = max(wave_inclusive_max_scan(ti[k]), tile_carry);   // >= 1: candidate 0 is a head
+                        tile_carry = (uint32_t)__builtin_amdgcn_readlane((int)run, 63);
+                        ti[k] = run - 1u;
                     }
 #pragma unroll
                     for (int k = 0; k < kXRounds; k++) inf[k] = s_tinfo[ti[k]];

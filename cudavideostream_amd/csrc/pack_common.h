@@ -23,6 +23,22 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
     return v;
 }
 
+// inclusive running maximum over the lanes (unsigned; lanes without a source take 0, the identity)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_max(uint32_t v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return v > o ? v : o;
+}
+__device__ __forceinline__ uint32_t wave_inclusive_max_scan(uint32_t v) {
+    v = dpp_max<0x111, 0xf>(v);
+    v = dpp_max<0x112, 0xf>(v);
+    v = dpp_max<0x114, 0xf>(v);
+    v = dpp_max<0x118, 0xf>(v);
+    v = dpp_max<0x142, 0xa>(v);
+    v = dpp_max<0x143, 0xc>(v);
+    return v;
+}
+
 // v_writelane_b32: put a wave-uniform value into one lane of a VGPR (1 instruction instead of
 // v_mov + v_cndmask); `lane` must be a compile-time constant here.
 __device__ __forceinline__ void write_lane(uint32_t &v, uint32_t uniform_value, int lane) {
@@ -33,10 +49,14 @@ __device__ __forceinline__ void write_lane(uint32_t &v, uint32_t uniform_value, 
 // ---- per-dword byte arithmetic (4 bytes per instruction) --------------------------------------------
 constexpr uint32_t kH = 0x80808080u, kL = 0x7f7f7f7fu;
 
-struct ThrConst {   // per-byte replicated constants of the threshold T (0..127)
-    uint32_t ca;    // 127 - T : (x_l + ca) carries into bit 7  <=>  x_l >= T + 1
-    uint32_t cb;    // T       : (x_l + cb) carries into bit 7  <=>  x_l >= 128 - T
+struct ThrConst {   // per-byte replicated constants of T' = T (T <= 127) or T - 128 (T >= 128: the HIGH form)
+    uint32_t ca;    // 127 - T' : (x_l + ca) carries into bit 7  <=>  x_l >= T' + 1
+    uint32_t cb;    // T'       : (x_l + cb) carries into bit 7  <=>  x_l >= 128 - T'
 };
+__host__ __device__ inline ThrConst make_thr(uint32_t thr /* 0..255 */) {
+    const uint32_t t = thr & 127u;
+    return ThrConst{(127u - t) * 0x01010101u, t * 0x01010101u};
+}
 
 // v_bitop3_b32: arbitrary 3-input boolean function; the truth table is written as an expression over
 // the three operand patterns TA, TB, TC (same convention as the instruction's immediate).
@@ -52,7 +72,10 @@ __device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
 //   The true difference d = 128 (a7 - s7) + x - 128 is classified by its sign and by |d| >= 128:
 //     sure = (a7 ^ s7) & ~(a7 ^ x7)          |d| >= 128
 //     pos  = (a7 & ~s7) | (~(a7 ^ s7) & x7)  d >= 0 (else d < 0), |d| < 128, |d| mod 128 in x_l
-//     flagged = sure | (pos ? x_l >= T + 1 : x_l < 128 - T)
+//     flagged = sure | (pos ? x_l >= T + 1 : x_l < 128 - T)                       T <= 127
+//     flagged = sure & (pos ? x_l >= T' + 1 : x_l < 128 - T'),  T' = T - 128       T >= 128 (HIGH): |d| = 128 + x_l
+//               for d >= 0 and 256 - x_l for d < 0 once |d| >= 128; |d| == 128 exactly (not "sure") is never > T
+template <bool HIGH = false>
 __device__ __forceinline__ uint32_t dword_flags(uint32_t a, uint32_t s, ThrConst tc, uint32_t &x) {
     x = (a | kH) - (s & kL);
     const uint32_t xl = x & kL;
@@ -61,7 +84,7 @@ __device__ __forceinline__ uint32_t dword_flags(uint32_t a, uint32_t s, ThrConst
     const uint32_t sure = bitop3<(TA ^ TB) & ~(TA ^ TC)>(a, s, x);
     const uint32_t pos = bitop3<(TA & ~TB) | (~(TA ^ TB) & TC)>(a, s, x);
     const uint32_t mag = bitop3<(TA & TB) | (~TA & ~TC)>(pos, A, nB);
-    return bitop3<(TA | TB) & TC>(sure, mag, kH);
+    return HIGH ? bitop3<(TA & TB) & TC>(sure, mag, kH) : bitop3<(TA | TB) & TC>(sure, mag, kH);
 }
 
 // per-byte (a - s) mod 256 from x: low 7 bits are x's, bit 7 is a7 ^ s7 ^ ~x7

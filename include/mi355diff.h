@@ -46,7 +46,7 @@ typedef struct mi355_core mi355_core;
 typedef struct mi355_config {
     int32_t width;      /* pixels */
     int32_t height;     /* pixels */
-    int32_t threshold;  /* LR_THRESHOLDS, server/include/common.h:14 (20); strict >, 0..127 */
+    int32_t threshold;  /* LR_THRESHOLDS, server/include/common.h:14 (20); strict >, 0..255 (255 flags nothing) */
     int32_t max_batch;  /* largest nframes of a *_batch call; sizes the workspace (>= 1) */
     int32_t device;     /* HIP device ordinal, or -1 for the current device */
     int32_t noise_filter; /* != 0: exec() runs the 3x3 convolution first (NOISE_FILTER, common.h:5) */

@@ -89,11 +89,34 @@ def test_static_flip_and_dense(po):
         assert 0.8 < off[1] / n < 0.9
 
 
-@pytest.mark.parametrize("thr", [0, 1, 20, 21, 127])
+@pytest.mark.parametrize("thr", [0, 1, 20, 21, 127, 128, 129, 200, 254, 255])
 def test_thresholds(po, thr):
+    """Every byte pair at thresholds either side of 128 (the reference's LR_THRESHOLDS is an unconstrained int,
+    common.h:14): 128 and above take the HIGH form of the 4-bytes-per-instruction compare; 255 flags nothing."""
     cur, prev = synth.edge_strip(3)
     with CUDACore(256, 256, threshold=thr, max_batch=1) as core:
-        check_stream(po, core, prev, cur[None, :], thr=thr)
+        off = check_stream(po, core, prev, cur[None, :], thr=thr)
+        if thr == 255:
+            assert off[-1] == 0
+
+
+def test_threshold_range_is_0_to_255():
+    for bad in (-1, 256, 1000):
+        with pytest.raises(lib.Mi355Error):
+            CUDACore(16, 16, threshold=bad)
+
+
+def test_high_threshold_stream_with_pairs_and_ragged_tiles(po):
+    """Threshold 150 on a stateful stream and on stateless pairs of a geometry with a partial last tile."""
+    w, h, T = 97, 13, 5
+    rng = np.random.default_rng(150)
+    base = rng.integers(0, 256, 3 * w * h, dtype=np.uint8)
+    frames = rng.integers(0, 256, (T, 3 * w * h), dtype=np.uint8)
+    with CUDACore(w, h, threshold=150, max_batch=T) as core:
+        check_stream(po, core, base, frames, thr=150)
+        off, xs, df, _ = run_stream(core, frames, pair_prev=np.roll(frames, 1, axis=0))
+        eo, exs, edf = oracle_pairs(po, frames, np.roll(frames, 1, axis=0), thr=150)
+        assert np.array_equal(off, eo) and np.array_equal(xs, exs) and np.array_equal(df, edf)
 
 
 def test_pair_mode_refrand(po):
