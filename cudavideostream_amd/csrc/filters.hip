@@ -47,6 +47,70 @@ __device__ __forceinline__ void store_px16(uint8_t *p, const Px16 &r, int nbytes
     }
 }
 
+// The same 48 bytes per lane, but leaving as three WAVE-CONTIGUOUS 1 KiB stores: the lanes' 48-byte pieces are
+// regrouped through the wave's 3 KiB of LDS (lane l then stores bytes 16 l + 1024 j, j = 0..2, of the wave's block).
+// A store instruction whose lanes write 16 bytes at a 48-byte stride touches 24 cache lines a third each; three of
+// those per wave write every line three times over.  `wave_base` = address of the wave's first byte; every lane of
+// the wave must take part (caller checks with a ballot).  LDS: ds_write_b128 at a 48-byte stride is conflict-free
+// per 16 lanes (12 l mod 64 covers the 64 banks in 16 disjoint groups of 4).
+#ifndef MI355_FILT_LDS_STORE
+#define MI355_FILT_LDS_STORE 1
+#endif
+__device__ __forceinline__ void store_px16_wave(uint8_t *wave_base, const Px16 &r, uint4 *lds /* 192 per wave */) {
+    const uint32_t lane = threadIdx.x & 63u;
+    lds[lane * 3u + 0u] = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
+    lds[lane * 3u + 1u] = make_uint4(r.w[4], r.w[5], r.w[6], r.w[7]);
+    lds[lane * 3u + 2u] = make_uint4(r.w[8], r.w[9], r.w[10], r.w[11]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint4 *q = reinterpret_cast<uint4 *>(wave_base);
+#pragma unroll
+    for (uint32_t j = 0; j < 3; j++) q[j * 64u + lane] = lds[j * 64u + lane];
+}
+
+// The load side of the same regrouping: three wave-contiguous 1 KiB loads, the lanes' 48-byte pieces read back from LDS.
+// Measured (profiles/r03t_filters_lds_ab.log): no gain for gray / binarize / red, the heat map slower (its LUT also
+// lives in LDS) -- the caches already serve the strided loads; kept as a build option, off.
+#ifndef MI355_FILT_LDS_LOAD
+#define MI355_FILT_LDS_LOAD 0
+#endif
+__device__ __forceinline__ Px16 load_px16_full(const uint8_t *in, size_t off) {
+#if MI355_FILT_LDS_LOAD
+    __shared__ uint4 s_l[4][192];
+    if (__ballot(true) == ~0ull) {   // the whole wave is here
+        const uint32_t lane = threadIdx.x & 63u;
+        uint4 *lds = s_l[threadIdx.x >> 6];
+        const uint4 *q = reinterpret_cast<const uint4 *>(in + off - (size_t)lane * 48u);
+        const uint4 a = q[lane], b = q[64u + lane], c = q[128u + lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the piece read back by the call before
+        __builtin_amdgcn_wave_barrier();
+        lds[lane] = a; lds[64u + lane] = b; lds[128u + lane] = c;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint4 x = lds[lane * 3u], y = lds[lane * 3u + 1u], z = lds[lane * 3u + 2u];
+        Px16 r;
+        r.w[0] = x.x; r.w[1] = x.y; r.w[2] = x.z; r.w[3] = x.w;
+        r.w[4] = y.x; r.w[5] = y.y; r.w[6] = y.z; r.w[7] = y.w;
+        r.w[8] = z.x; r.w[9] = z.y; r.w[10] = z.z; r.w[11] = z.w;
+        return r;
+    }
+#endif
+    return load_px16<true>(in + off, 48);
+}
+
+// A lane's 48 bytes at out + off, through the wave-contiguous form when every lane of the wave stores a full piece.
+// `take` = this lane takes part (full 16 pixels, 16-byte aligned frame); lanes that do not fall back by themselves.
+__device__ __forceinline__ void store_px16_full(uint8_t *out, size_t off, const Px16 &q) {
+#if MI355_FILT_LDS_STORE
+    __shared__ uint4 s_t[4][192];
+    if (__ballot(true) == ~0ull) {   // the whole wave is here
+        store_px16_wave(out + off - (size_t)(threadIdx.x & 63u) * 48u, q, s_t[threadIdx.x >> 6]);
+        return;
+    }
+#endif
+    store_px16<true>(out + off, q, 48);
+}
+
 __device__ __forceinline__ uint32_t get_byte(const Px16 &r, int i) {  // i is a compile-time constant
     return (r.w[i >> 2] >> (8 * (i & 3))) & 0xffu;
 }
@@ -109,7 +173,7 @@ __global__ __launch_bounds__(256) void k_gray(const uint8_t *in, uint8_t *out, u
     const uint32_t rem = npix - lane_px;
     const size_t off = (size_t)lane_px * 3;
     if (FAST && rem >= 16) {
-        const Px16 p = load_px16<true>(in + off, 48);
+        const Px16 p = load_px16_full(in, off);
         Px16 q;
 #pragma unroll
         for (int i = 0; i < 12; i++) q.w[i] = 0;
@@ -119,7 +183,7 @@ __global__ __launch_bounds__(256) void k_gray(const uint8_t *in, uint8_t *out, u
                 gray_of<WEIGHTED>(get_byte(p, 3 * k), get_byte(p, 3 * k + 1), get_byte(p, 3 * k + 2));
             put_byte(q, 3 * k, v); put_byte(q, 3 * k + 1, v); put_byte(q, 3 * k + 2, v);
         }
-        store_px16<true>(out + off, q, 48);
+        store_px16_full(out + 0, off, q);
     } else {
         const uint32_t cntpx = rem < 16 ? rem : 16;
         for (uint32_t k = 0; k < cntpx; k++) {
@@ -311,7 +375,7 @@ __global__ __launch_bounds__(256) void k_gray_binarize(const uint8_t *in, uint8_
     const uint32_t rem = npix - lane_px;
     const size_t off = (size_t)lane_px * 3;
     if (FAST && rem >= 16) {
-        const Px16 p = load_px16<true>(in + off, 48);
+        const Px16 p = load_px16_full(in, off);
         Px16 q;
 #pragma unroll
         for (int i = 0; i < 12; i++) q.w[i] = 0;
@@ -322,7 +386,7 @@ __global__ __launch_bounds__(256) void k_gray_binarize(const uint8_t *in, uint8_
             const uint32_t v = g > thr ? 255u : 0u;
             put_byte(q, 3 * k, v); put_byte(q, 3 * k + 1, v); put_byte(q, 3 * k + 2, v);
         }
-        store_px16<true>(out + off, q, 48);
+        store_px16_full(out, off, q);
     } else {
         const uint32_t cntpx = rem < 16 ? rem : 16;
         for (uint32_t k = 0; k < cntpx; k++) {
@@ -357,7 +421,7 @@ __global__ __launch_bounds__(256) void k_binarize_gray1(const uint8_t *gray1, si
             const uint32_t v = ((gw[k >> 2] >> (8 * (k & 3))) & 0xffu) > thr ? 255u : 0u;
             put_byte(q, 3 * k, v); put_byte(q, 3 * k + 1, v); put_byte(q, 3 * k + 2, v);
         }
-        store_px16<true>(out + off, q, 48);
+        store_px16_full(out, off, q);
     } else {
         const uint32_t cntpx = rem < 16 ? rem : 16;
         for (uint32_t k = 0; k < cntpx; k++) {
@@ -451,8 +515,8 @@ __global__ __launch_bounds__(256) void k_heat_map(const uint8_t *cur, const uint
     const size_t off = (size_t)lane_px * 3;
     const bool full = FAST && rem >= 16;
     const int nb = full ? 48 : (int)(rem < 16 ? rem : 16) * 3;
-    const Px16 c = full ? load_px16<true>(cur + off, 48) : load_px16<false>(cur + off, nb);
-    const Px16 p = full ? load_px16<true>(prev + off, 48) : load_px16<false>(prev + off, nb);
+    const Px16 c = full ? load_px16_full(cur, off) : load_px16<false>(cur + off, nb);
+    const Px16 p = full ? load_px16_full(prev, off) : load_px16<false>(prev + off, nb);
     Px16 q;
 #pragma unroll
     for (int i = 0; i < 12; i++) q.w[i] = 0;
@@ -468,7 +532,7 @@ __global__ __launch_bounds__(256) void k_heat_map(const uint8_t *cur, const uint
         put_byte(q, 3 * k + 1, s_lut[d * 3 + 1]);                  // cpu.cu:63  G
         put_byte(q, 3 * k + 2, s_lut[d * 3 + 2]);                  // cpu.cu:64  R
     }
-    if (full) store_px16<true>(out + off, q, 48);
+    if (full) store_px16_full(out, off, q);
     else store_px16<false>(out + off, q, nb);
 }
 
@@ -496,8 +560,8 @@ __global__ __launch_bounds__(256) void k_red_dense(const uint8_t *cur, const uin
     const size_t off = (size_t)lane_px * 3;
     const bool full = FAST && rem >= 16;
     const int nb = full ? 48 : (int)(rem < 16 ? rem : 16) * 3;
-    const Px16 c = full ? load_px16<true>(cur + off, 48) : load_px16<false>(cur + off, nb);
-    const Px16 p = full ? load_px16<true>(prev + off, 48) : load_px16<false>(prev + off, nb);
+    const Px16 c = full ? load_px16_full(cur, off) : load_px16<false>(cur + off, nb);
+    const Px16 p = full ? load_px16_full(prev, off) : load_px16<false>(prev + off, nb);
     Px16 q;
 #pragma unroll
     for (int i = 0; i < 12; i++) q.w[i] = 0;
@@ -512,7 +576,7 @@ __global__ __launch_bounds__(256) void k_red_dense(const uint8_t *cur, const uin
         }
         put_byte(q, 3 * k + 2, f ? 255u : 0u);                     // cpu.cu:46-52
     }
-    if (full) store_px16<true>(out + off, q, 48);
+    if (full) store_px16_full(out, off, q);
     else store_px16<false>(out + off, q, nb);
 }
 
