@@ -54,7 +54,12 @@ typedef struct mi355_config {
     int32_t flags;      /* MI355_FLAG_*; 0 = defaults */
 } mi355_config;
 
-/* Experiment, off by default: mi355_diff_stream_batch as ONE resident kernel instead of the three-kernel log
+/* The two flags below select EXPERIMENTS that are only in a library built with `make EXPERIMENTS=1`; the default
+ * build refuses them (MI355_ERR_INVALID).  Both kernels wait for each other with bounded spins; a wait that expires
+ * leaves the batch's output (and, for FUSED, the state) undefined and is reported ONLY by mi355_synchronize
+ * (MI355_ERR_STATE; the core then falls back to the log path): a caller of the experiments synchronises with
+ * mi355_synchronize, not through a stream of its own.  Thresholds 0..127 only.
+ * Experiment, off by default: mi355_diff_stream_batch as ONE resident kernel instead of the three-kernel log
  * path, when the frame fits the device (every workgroup must be resident at once; 1080p fits).  Bit-exact with
  * the log path and slower on the MI355X (csrc/diff_fused.hip says why).  Also MI355_FUSED=1 in the environment. */
 #define MI355_FLAG_FUSED 1
