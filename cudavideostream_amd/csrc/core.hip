@@ -533,6 +533,7 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (!rc) { e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipStreamCreate", e); }
     c->stream = c->own_stream;
     for (int i = 0; i < mi355_core::kEvRing * mi355_core::kEvPer && !rc; i++) { e = hipEventCreate(&c->ev[i / mi355_core::kEvPer][i % mi355_core::kEvPer]); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipEventCreate", e); }
+    if (!rc && (e = init_gray_table()) != hipSuccess) rc = fail(MI355_ERR_HIP, "init_gray_table", e);
     if (!rc) rc = dev_alloc(c, &c->state, N + 16);
     if (!rc) rc = dev_alloc(c, &c->in, N + 16);
     if (!rc) rc = dev_alloc(c, &c->aux, N + 16);

@@ -5,6 +5,8 @@
 // (48 B = three 16-B loads) per lane, grid-stride free (one pass), no atomics except the histogram.
 // This file is compiled with -ffp-contract=off: the weighted grayscale and the convolution depend on
 // separate multiply and add roundings.
+#include <mutex>
+
 #include "internal.h"
 
 namespace mi355 {
@@ -154,13 +156,66 @@ hipError_t launch_int_diff(const int32_t *cur, const int32_t *prev, int32_t *out
 // weighted == tests/grayscale-weighted/cpu.cu:40      (uint8)(0.114*B + 0.587*G + 0.299*R) in double,
 //             left to right, no contraction (the reference GPU kernel's float accumulator rounds
 //             differently and is not the oracle).
+// ---- weighted gray in integers ------------------------------------------------------------------------------------
+// The oracle is the double expression of tests/grayscale-weighted/cpu.cu:40, uint8(0.114*B + 0.587*G + 0.299*R),
+// evaluated left to right and truncated.  With K = 114 B + 587 G + 299 R the exact value is K / 1000; it is at least
+// 0.001 away from an integer unless 1000 | K, far more than the double evaluation's error, so the result is
+// floor(K / 1000) -- except for some of the 16 774 triples with 1000 | K, where the three rounded products add up to
+// just below the integer and the truncation lands one lower: 1957 triples (tests/test_oracle.py counts them).
+// For a given (B, G) at most one R in 0..255 makes K a multiple of 1000 (299 is invertible mod 1000), so the
+// exceptions fit a 256 x 256 table of that R (0xFFFF: none), built on the host WITH the double expression
+// (fill_gray_exceptions) -- 128 KB, resident in L2; only the one pixel in a thousand whose K is a multiple of 1000
+// looks at it.  floor(K / 1000) = ((K >> 3) * 33555) >> 22 for K <= 255 000 (33555 = ceil(2^22 / 125), error
+// K/8 * (33555 * 125 - 2^22) / (125 * 2^22) < 1/125).  9 integer instructions per pixel instead of 3 conversions,
+// 3 multiplications and 2 additions in fp64 (every one of them in the slow instruction class) and a conversion back.
+// Proven on all 2^24 triples: tests/test_oracle.py::test_integer_gray_equals_the_double_expression (CPU),
+// tests/test_filters_gpu.py::test_gray_weighted_exhaustive_2_24 (device).
+__device__ uint16_t g_gray_exc[65536];
+
+// Measured (profiles/r03w_gray_integer_ab.log): no faster -- the gray kernels run at the memory system's rate either
+// way (2.15 us per 1080p frame), and the histogram pass of the fused chain is 4 % SLOWER in integers (3.37 against
+// 3.25 us for the chain): the rare table look-up is a dependent L2 access in the middle of a streaming kernel.
+// The product therefore keeps the fp64 form; -DMI355_GRAY_FP64=0 builds the integer one (bit-exact: the exhaustive
+// device test passes on it).
+#ifndef MI355_GRAY_FP64
+#define MI355_GRAY_FP64 1
+#endif
 template <bool WEIGHTED>
 __device__ __forceinline__ uint32_t gray_of(uint32_t b, uint32_t g, uint32_t r) {
     if (WEIGHTED) {
+#if MI355_GRAY_FP64
         const double v = 0.114 * (double)b + 0.587 * (double)g + 0.299 * (double)r;
         return (uint32_t)v;
+#else
+        const uint32_t K = __umul24(b, 114u) + __umul24(g, 587u) + __umul24(r, 299u);
+        uint32_t q = ((K >> 3) * 33555u) >> 22;
+        if (K == q * 1000u && (uint32_t)g_gray_exc[(b << 8) | g] == r) q -= 1u;
+        return q;
+#endif
     }
     return (b + g + r) / 3u;
+}
+
+// Host side: the exception table from the double expression itself.
+static void fill_gray_exceptions(uint16_t *t) {
+    for (uint32_t b = 0; b < 256; b++)
+        for (uint32_t g = 0; g < 256; g++) {
+            t[(b << 8) | g] = 0xFFFFu;
+            // the R with 114 b + 587 g + 299 R = 0 (mod 1000): R = -(114 b + 587 g) * 699 (mod 1000), 299 * 699 = 1 (mod 1000)
+            const uint32_t r = (1000u - (114u * b + 587u * g) % 1000u) % 1000u * 699u % 1000u;
+            if (r > 255u) continue;
+            const uint32_t K = 114u * b + 587u * g + 299u * r;   // a multiple of 1000
+            volatile double v = 0.114 * (double)b + 0.587 * (double)g;
+            v = v + 0.299 * (double)r;
+            if ((uint32_t)v != K / 1000u) t[(b << 8) | g] = (uint16_t)r;
+        }
+}
+
+hipError_t init_gray_table() {   // once per device (called by mi355_create with the device current)
+    static uint16_t host[65536];
+    static std::once_flag once;
+    std::call_once(once, [] { fill_gray_exceptions(host); });
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_gray_exc), host, sizeof host);
 }
 
 // Batched launches: blockIdx.y is the frame, frame f lives at base + f*stride.

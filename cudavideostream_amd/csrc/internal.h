@@ -142,6 +142,7 @@ struct FrameBatch {
 };
 hipError_t launch_int_diff(const int32_t *cur, const int32_t *prev, int32_t *out, size_t n,
                            hipStream_t s);
+hipError_t init_gray_table();   // the weighted gray's exception table on the current device
 hipError_t launch_gray(const uint8_t *in, uint8_t *out, uint32_t npix, bool weighted, FrameBatch fb,
                        hipStream_t s);
 hipError_t launch_binarize_chain(const uint8_t *gray, uint8_t *out, uint32_t nbytes, int32_t *hist,

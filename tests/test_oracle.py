@@ -395,3 +395,32 @@ def test_cpu_branch_matches_reference_run_at_1080p(po):
         assert int((out == 255).sum()) == int(g["white"][t])
         if int(g["thr"][t]) >= 0:
             assert int(thr) == int(g["thr"][t])
+
+
+def test_integer_gray_equals_the_double_expression():
+    """The integer form of the weighted gray the kernels use (csrc/filters.hip, gray_of): floor(K / 1000) by
+    multiply-shift, K = 114 B + 587 G + 299 R, minus one for the triples of the exception table -- against the double
+    expression of tests/grayscale-weighted/cpu.cu:40 on all 2^24 triples.  The table is rebuilt here the way
+    fill_gray_exceptions builds it: for every (B, G) the one R in 0..255 that makes K a multiple of 1000, kept when
+    the double expression truncates below K / 1000."""
+    x = np.arange(1 << 24, dtype=np.int64)
+    B, G, R = x & 255, (x >> 8) & 255, x >> 16
+    ref = ((0.114 * B.astype(np.float64) + 0.587 * G) + 0.299 * R).astype(np.uint8)
+    K = 114 * B + 587 * G + 299 * R
+    q = ((K >> 3) * 33555) >> 22
+    assert np.array_equal(q, K // 1000)                                    # the multiply-shift is an exact division
+    # the table
+    bb, gg = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
+    rr = (1000 - (114 * bb + 587 * gg) % 1000) % 1000 * 699 % 1000
+    ok = rr <= 255
+    kk = 114 * bb + 587 * gg + 299 * np.where(ok, rr, 0)
+    assert np.all(kk[ok] % 1000 == 0)
+    dbl = ((0.114 * bb.astype(np.float64) + 0.587 * gg) + 0.299 * np.where(ok, rr, 0)).astype(np.int64)
+    table = np.where(ok & (dbl != kk // 1000), rr, 0xFFFF)
+    assert int((table != 0xFFFF).sum()) == 1957
+    # the kernel's rule
+    exc = (K == q * 1000) & (table[B, G] == R)
+    got = (q - exc).astype(np.uint8)
+    assert np.array_equal(got, ref)
+    # every mismatch of the plain floor is in the table, and only multiples of 1000 are
+    assert int((q.astype(np.uint8) != ref).sum()) == 1957 == int(exc.sum())
