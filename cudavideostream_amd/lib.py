@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355diff.so")
+# MI355DIFF_LIB: another build of the same library (A/B builds under build/ab/, the EXPERIMENTS=1 build) for the tests
+LIB_PATH = os.environ.get("MI355DIFF_LIB") or os.path.join(_HERE, "libmi355diff.so")
 
 OK = 0
 ERR_INVALID = -1
