@@ -42,8 +42,13 @@ namespace mi355 {
 #ifndef MI355_K1_PREFETCH
 #define MI355_K1_PREFETCH 4
 #endif
-constexpr int kPrefetch = MI355_K1_PREFETCH;  // frames per register group (two groups: 8 x 1 KiB in flight per wave)
-static_assert(kPrefetch % 2 == 0, "frames are processed in pairs");
+// Frames per register group (two groups per wave).  Stream mode: 4 (8 x 1 KiB in flight per wave, 58 VGPRs).  Pair
+// mode holds two operands per frame: with 4 it needed 89 VGPRs = 5 waves per SIMD, and the 6076 waves of a 1080p frame
+// no longer fitted the chip at once (5120 places): a sixth of them ran as a second generation, alone.  With 2 the
+// pair kernel fits 6 waves per SIMD like the stream kernel (the depth of the prefetch was measured not to matter).
+template <bool PAIR>
+struct PrefetchOf { static constexpr int value = PAIR ? (MI355_K1_PREFETCH > 2 ? 2 : MI355_K1_PREFETCH) : MI355_K1_PREFETCH; };
+static_assert(MI355_K1_PREFETCH % 2 == 0, "frames are processed in pairs");
 
 // ---- the log (round 3) ------------------------------------------------------------------------------
 // What k_diff_pack leaves for k_expand, per (frame, tile):
@@ -151,6 +156,7 @@ __device__ __forceinline__ uint32_t emit_step(const uint32_t (&dm)[4], uint32_t 
 // load makes the compiler fall back to s_waitcnt vmcnt(0) -- i.e. no prefetch.
 template <bool PAIR, bool FAST>
 struct Group {
+    static constexpr int kPrefetch = PrefetchOf<PAIR>::value;
     uint4 c[kPrefetch];
     uint4 p[kPrefetch];
 
@@ -176,6 +182,7 @@ template <bool PAIR, bool FAST, bool HIGH>
 __device__ __forceinline__ void pack_group(const PackArgs &a, const Group<PAIR, FAST> &g, int t0, uint4 &st,
                                            LogPos &lp, uint32_t tile, ThrConst tc, int lane, const LogOut &lg) {
     // The group's kPrefetch meta words are assembled in lanes 0..kPrefetch-1 and leave with ONE store.
+    constexpr int kPrefetch = PrefetchOf<PAIR>::value;
     uint4 meta = make_uint4(0, 0, 0, 0);
     const uint32_t lane24 = (uint32_t)lane << 24;
     const uint32_t jump = (a.ntiles - 1u) * 1024u;
@@ -230,6 +237,7 @@ __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint
     // flight.
     Group<PAIR, FAST> ga, gb;
     LogPos lp{tile * 1024u, 256u, tile * 1024u, 64u};   // codes / records this tile has appended to its logs so far
+    constexpr int kPrefetch = PrefetchOf<PAIR>::value;
     const size_t gstep = (size_t)kPrefetch * a.stride;
     const uint8_t *cur_last = a.cur + (size_t)(T - 1) * a.stride, *prev_last = PAIR ? a.prev + (size_t)(T - 1) * a.stride : nullptr;
     const uint8_t *cp = a.cur, *pp = a.prev;   // frame t0 + kPrefetch, the next group to request
