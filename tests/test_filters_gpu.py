@@ -30,9 +30,12 @@ def test_gray_heat_red(po, w, h):
     prv = np.clip(img.astype(int) + rng.integers(-60, 61, n), 0, 255).astype(np.uint8)
     d_img, d_prv = to_dev(img), to_dev(prv)
     with CUDACore(w, h) as core:
-        for fn, exp in ((core.gray_avg, po.gray_avg(img)), (core.gray_weighted, po.gray_weighted(img))):
+        # (the method is looked up AFTER the output buffer is made: the test wrapper drains torch's streams at the
+        # look-up, and torch.full above runs on torch's stream, the kernel on the core's own -- a method bound before
+        # dev_out() raced with the fill once in a dozen runs)
+        for name, exp in (("gray_avg", po.gray_avg(img)), ("gray_weighted", po.gray_weighted(img))):
             d_o = dev_out(n)
-            fn(d_img, d_o); core.synchronize()
+            getattr(core, name)(d_img, d_o); core.synchronize()
             assert np.array_equal(d_o.cpu().numpy(), exp)
         d_o = dev_out(n)
         core.heat_map(d_img, d_prv, d_o); core.synchronize()
