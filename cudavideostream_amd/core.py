@@ -280,6 +280,12 @@ class CUDACore:
         _l.check(self._lib.mi355_get_kernel_timing(self._h, C.byref(a), C.byref(b), C.byref(d), C.byref(n)))
         return a.value, b.value, d.value, n.value
 
+    def probe_clock(self, milliseconds=200):
+        """Shader clock (MHz) the device holds under an integer-VALU load (csrc/diag.hip)."""
+        mhz = C.c_double(0)
+        _l.check(self._lib.mi355_probe_clock(self._h, int(milliseconds), C.byref(mhz)))
+        return mhz.value
+
     def get_timing(self):
         """(ms in the diff/threshold/pack kernel, ms in pack+scan+gather, launches) since reset."""
         a, b, n = C.c_double(0), C.c_double(0), C.c_int(0)

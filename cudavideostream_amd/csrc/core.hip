@@ -124,6 +124,7 @@ struct mi355_core {
     hipEvent_t side_done = nullptr;   // == the `expanded` event of the last pipelined batch, or null: nothing pending
     bool pipeline_ok = true;          // false: MI355_PIPELINE=0, or the second set could not be allocated
     uint32_t k1_blocks = 0;           // pipelined batches: workgroups of the pack kernel (0 = one tile per wave)
+    bool scan_on_main = false;        // pipelined batches: the index kernel runs on the core's stream, between two pack kernels
 
     // timing: ring of event sets {before pack, after pack, before scan, after scan, after expand}, harvested lazily
     // so that timed batches still queue back to back
@@ -344,6 +345,9 @@ int setup_pipeline(mi355_core *c) {
     const char *env = getenv("MI355_PIPELINE");
     if (env && env[0] == '0') { c->pipeline_ok = false; return MI355_OK; }
     if (const char *b = getenv("MI355_K1_BLOCKS")) c->k1_blocks = (uint32_t)atoi(b);   // tuning knob (tools/, profiles/)
+    if (const char *b = getenv("MI355_SCAN_MAIN")) c->scan_on_main = b[0] == '1';
+    int side_prio = 0;
+    if (const char *b = getenv("MI355_SIDE_PRIO")) side_prio = atoi(b);   // 1: the side stream gets the highest stream priority
     const size_t T = (size_t)c->cfg.max_batch, W = c->ntiles;
     mi355_core::LogSet &s0 = c->set[0], &s1 = c->set[1];
     s0.rec = c->rec; s0.codes = c->codes; s0.meta = c->meta; s0.groff = c->groff; s0.totals = c->totals;
@@ -353,7 +357,13 @@ int setup_pipeline(mi355_core *c) {
     ok = ok && hipMalloc((void **)&s1.groff, T * expand_groups(c->ntiles) * 16) == hipSuccess;
     ok = ok && hipMalloc((void **)&s1.totals, (T + 1) * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(s1.totals, 0, (T + 1) * sizeof(uint32_t)) == hipSuccess;   // the scan kernel's ticket
-    ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+    if (side_prio) {
+        int lo = 0, hi = 0;
+        ok = ok && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
+        ok = ok && hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi) == hipSuccess;
+    } else {
+        ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+    }
     for (int i = 0; i < 2 && ok; i++) {
         ok = hipEventCreateWithFlags(&c->set[i].packed, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->set[i].expanded, hipEventDisableTiming) == hipSuccess;
@@ -453,17 +463,28 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     a.meta = ls.meta;
     a.rec_bytes = (uint32_t)((size_t)c->cfg.max_batch * c->ntiles * 1024u);
     a.meta_bytes = (uint32_t)((size_t)c->cfg.max_batch * c->ntiles * 16u);
-    const bool aligned = (((uintptr_t)d_cur | (uintptr_t)d_prev | stride) & 15u) == 0;
+    // the vector path of the pack kernel: 16-byte aligned operands, and a group of four frames within reach of one
+    // buffer descriptor's 32-bit offsets (diff_pack.hip, Group::load_desc)
+    const bool aligned = (((uintptr_t)d_cur | (uintptr_t)d_prev | stride) & 15u) == 0 && 3 * (uint64_t)stride + c->n < (1ull << 32);
     HIP_TRY(launch_diff_pack(a, pair, aligned, pipelined ? c->k1_blocks : 0u, c->stream));
     if (tev) HIP_TRY(hipEventRecord(tev[1], c->stream));
-    if (pipelined) {
+    // The index kernel is short (12 us alone) and gates the expansion: behind the next batch's pack kernel on the side
+    // stream it waits for wave slots and for memory round trips that take ten times as long there; on the core's
+    // stream it runs before the next pack kernel starts.
+    const bool scan_main = pipelined && c->scan_on_main;
+    hipStream_t ss = scan_main ? c->stream : tail;
+    if (pipelined && !scan_main) {
         HIP_TRY(hipEventRecord(ls.packed, c->stream));
         HIP_TRY(hipStreamWaitEvent(tail, ls.packed, 0));
     }
-    if (tev) HIP_TRY(hipEventRecord(tev[2], tail));
+    if (tev) HIP_TRY(hipEventRecord(tev[2], ss));
     HIP_TRY(launch_scan(ls.meta, ls.groff, ls.totals, c->ntiles, nframes, (uint32_t *)d_offsets,
-                        ls.totals + c->cfg.max_batch, tail));
-    if (tev) HIP_TRY(hipEventRecord(tev[3], tail));
+                        ls.totals + c->cfg.max_batch, ss));
+    if (tev) HIP_TRY(hipEventRecord(tev[3], ss));
+    if (scan_main) {
+        HIP_TRY(hipEventRecord(ls.packed, c->stream));
+        HIP_TRY(hipStreamWaitEvent(tail, ls.packed, 0));
+    }
     ExpandArgs g{};
     g.rec = ls.rec;
     g.codes = ls.codes;
@@ -471,6 +492,8 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     g.roff = ls.groff;
     g.offsets = (const uint32_t *)d_offsets;
     g.ntiles = c->ntiles;
+    g.codes_bytes = a.codes_bytes;
+    g.rec_bytes = a.rec_bytes;
     g.out_xs = (int32_t *)d_xs;
     g.out_diff = (uint8_t *)d_diff;
     g.wire = (uint8_t *)d_wire;

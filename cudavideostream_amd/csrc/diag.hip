@@ -1,0 +1,74 @@
+// diag.hip -- diagnostics behind the C-ABI (include/mi355diff.h, "measurement"): the shader clock the chip holds
+// under an integer-VALU load.
+//
+// Why: the diff/threshold/pack path is bound by instruction issue, so its time follows the
+// shader clock, and MI355X boards hold different clocks under the same load (the chip lowers its clock under load;
+// devices differ by up to ~12 %, MI355X_MICROARCH.md "DVFS give-back").  bench.py prints this figure next to its
+// frames/s so that a box-to-box spread of the headline can be told from a change of the code.
+//
+// Method (the guide's item 6): stamp s_memtime (shader cycles) and s_memrealtime (a constant 100 MHz counter) around
+// a loop of plain integer instructions in every wave; clock = d(memtime) / d(memrealtime) x 100 MHz, median over the
+// waves.  The stamps go to a buffer of their own that nothing else reads; the kernel is not part of any product path.
+#include <algorithm>
+#include <vector>
+
+#include "../../include/mi355diff.h"
+#include "internal.h"
+
+namespace mi355 {
+
+__global__ __launch_bounds__(256) void k_clock_probe(uint64_t *stamps, uint32_t iters, uint32_t seed) {
+    uint32_t a = threadIdx.x * 2654435761u + seed, b = blockIdx.x + 17u, c = a ^ 0x9e3779b9u, d = b + a;
+    const uint64_t c0 = __builtin_amdgcn_s_memtime();
+    const uint64_t r0 = __builtin_amdgcn_s_memrealtime();
+    for (uint32_t i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {   // four independent chains of the pack kernel's instruction classes
+            a = (a | 0x80808080u) - (b & 0x7f7f7f7fu);
+            b = __builtin_amdgcn_bitop3_b32(b, c, d, 0xb2);
+            c = (c + a) ^ (d >> 3);
+            d = __builtin_amdgcn_perm(d, a, 0x07020500u) + b;
+        }
+    }
+    const uint64_t c1 = __builtin_amdgcn_s_memtime();
+    const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {
+        const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        stamps[2 * w] = c1 - c0;
+        stamps[2 * w + 1] = r1 - r0;
+    }
+    if ((a ^ b ^ c ^ d) == 0x12345u && iters == 0xffffffffu) stamps[0] = a;   // keeps the chains alive
+}
+
+}  // namespace mi355
+
+using namespace mi355;
+
+extern "C" int mi355_probe_clock(mi355_core *c, int milliseconds, double *shader_mhz) {
+    if (!c || !shader_mhz) return set_error(MI355_ERR_INVALID, "null argument");
+    if (milliseconds < 1 || milliseconds > 2000) return set_error(MI355_ERR_INVALID, "milliseconds outside [1, 2000]");
+    hipStream_t s = core_stream(c);
+    hipDeviceProp_t prop{};
+    if (hipGetDeviceProperties(&prop, core_device(c)) != hipSuccess) return set_error(MI355_ERR_HIP, "hipGetDeviceProperties");
+    const int blocks = prop.multiProcessorCount * 4;   // 4 waves per SIMD
+    const size_t waves = (size_t)blocks * 4;
+    uint64_t *d = nullptr;
+    if (hipMalloc((void **)&d, waves * 16) != hipSuccess) return set_error(MI355_ERR_HIP, "hipMalloc(stamps)");
+    // 64 instructions per iteration and wave, 4 waves per SIMD, ~2.5-4.5 cycles each: ~800 cycles per iteration
+    const uint32_t iters = (uint32_t)((double)milliseconds * 2.0e6 / 800.0);
+    std::vector<uint64_t> h(waves * 2);
+    hipLaunchKernelGGL(k_clock_probe, dim3(blocks), dim3(256), 0, s, d, iters, 1u);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d, waves * 16, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) return set_error(MI355_ERR_HIP, "clock probe");
+    std::vector<double> mhz;
+    mhz.reserve(waves);
+    for (size_t w = 0; w < waves; w++)
+        if (h[2 * w + 1]) mhz.push_back((double)h[2 * w] / (double)h[2 * w + 1] * 100.0);
+    if (mhz.empty()) return set_error(MI355_ERR_STATE, "clock probe: no stamps");
+    std::nth_element(mhz.begin(), mhz.begin() + mhz.size() / 2, mhz.end());
+    *shader_mhz = mhz[mhz.size() / 2];
+    return MI355_OK;
+}

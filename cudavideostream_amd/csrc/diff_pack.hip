@@ -29,6 +29,9 @@
 //                 LDS stage and coalesced stores.
 // No spin waits; the only inter-workgroup communication is the completion ticket of k_scan_groups;
 // results are independent of dispatch order.
+#include <cstdio>
+#include <vector>
+
 #include "pack_common.h"
 
 namespace mi355 {
@@ -41,6 +44,12 @@ namespace mi355 {
 
 #ifndef MI355_K1_PREFETCH
 #define MI355_K1_PREFETCH 4
+#endif
+#ifndef MI355_K1PRIO
+#define MI355_K1PRIO 0
+#endif
+#ifndef MI355_K1_PAD     // timing builds: this many extra vector instructions per frame and tile (what does an instruction cost?)
+#define MI355_K1_PAD 0
 #endif
 // Frames per register group (two groups per wave).  Stream mode: 4 (8 x 1 KiB in flight per wave, 58 VGPRs).  Pair
 // mode holds two operands per frame: with 4 it needed 89 VGPRs = 5 waves per SIMD, and the 6076 waves of a 1080p frame
@@ -96,16 +105,22 @@ __device__ __forceinline__ void compare_step(const uint4 c, uint4 &s, ThrConst t
         // 0xFF in every flagged byte: a v_perm selector byte of 0x80 yields the constant 0xFF, one of 0x00
         // byte 0 of the second operand (0)
         const uint32_t mask = __builtin_amdgcn_perm(0u, 0u, fh[k]);
-        dm[k] = bytes_sub_from_x(cw[k], sw[k], x) & mask;     // diff where flagged, 0 elsewhere
+        dm[k] = bytes_sub_from_x(cw[k], sw[k], x, tc.h) & mask;     // diff where flagged, 0 elsewhere
         // negative feedback (kernels.cu:316-331): flagged bytes take the current value, the others
         // keep the previous one -> the state is the frame the client reconstructs
         sw[k] = bitop3<(TA & TC) | (TB & ~TC)>(cw[k], sw[k], mask);
 #endif
     }
     s = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+#if MI355_K1_PAD
+    { uint32_t pad = cw[0];
+#pragma unroll
+      for (int i = 0; i < MI355_K1_PAD; i++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(pad) : "v"(cw[1]));
+      asm volatile("" :: "v"(pad)); }
+#endif
     // flags are 0x80 per flagged byte: two v_dot4 chains weigh them into 128 * (map of 8 bytes)
-    const uint32_t lo = __builtin_amdgcn_udot4(fh[1], 0x80402010u, __builtin_amdgcn_udot4(fh[0], 0x08040201u, 0u, false), false);
-    const uint32_t hi = __builtin_amdgcn_udot4(fh[3], 0x80402010u, __builtin_amdgcn_udot4(fh[2], 0x08040201u, 0u, false), false);
+    const uint32_t lo = __builtin_amdgcn_udot4(fh[1], tc.w1, __builtin_amdgcn_udot4(fh[0], tc.w0, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(fh[3], tc.w1, __builtin_amdgcn_udot4(fh[2], tc.w0, 0u, false), false);
     m16 = (lo + (hi << 8)) >> 7;
 }
 
@@ -159,6 +174,23 @@ struct Group {
     static constexpr int kPrefetch = PrefetchOf<PAIR>::value;
     uint4 c[kPrefetch];
     uint4 p[kPrefetch];
+
+    // Aligned tiles (round 4): the group's frames through ONE buffer descriptor that starts at the group's first frame
+    // and ends with the batch; voff[d] = the lane's byte offset + d * stride.  A frame costs no address arithmetic at
+    // all (round 3: 8 scalar instructions to clamp the frame pointer to the last frame + a 64-bit vector add per load;
+    // scalar instructions are not free on this chip: ~2.6 cycles of the SIMD's issue time each, profiles/r04n), and
+    // frames beyond the batch are out of the descriptor's range: they return zeros and read nothing.
+    __device__ __forceinline__ void load_desc(__amdgpu_buffer_rsrc_t cur, __amdgpu_buffer_rsrc_t prev, const uint32_t (&voff)[kPrefetch]) {
+#pragma unroll
+        for (int d = 0; d < kPrefetch; d++) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(cur, voff[d], 0, (!PAIR && MI355_NT_LOADS) ? 2 : 0);   // stream frames: read once (nt)
+            c[d] = make_uint4(v.x, v.y, v.z, v.w);
+            if (PAIR) {
+                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(prev, voff[d], 0, 0);
+                p[d] = make_uint4(w.x, w.y, w.z, w.w);
+            }
+        }
+    }
 
     // The frame bases are wave-uniform (SGPRs) and the lane's byte offset is a 32-bit VGPR: the loads use the
     // SGPR-base + VGPR-offset form.  `cur0` / `prev0` point at frame t0; frames beyond the batch repeat the last one.
@@ -227,7 +259,17 @@ template <bool PAIR, bool FAST, bool HIGH>
 __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint32_t byte_off,
                                           int valid, int lane) {
     const int T = a.nframes;
+#ifndef MI355_K1_VCONST
+#define MI355_K1_VCONST 0   // measured: 4 % SLOWER with the constants in vector registers (profiles/r04o): the kernel is not bound by its issue rate
+#endif
+#ifndef MI355_K1_DESC
+#define MI355_K1_DESC 1
+#endif
+#if MI355_K1_VCONST
+    const ThrConst tc = vgpr_consts(make_thr((uint32_t)a.thr));   // in vector registers: see vgpr_const
+#else
     const ThrConst tc = make_thr((uint32_t)a.thr);
+#endif
     const LogOut lg{make_rsrc(a.codes, a.codes_bytes), make_rsrc(a.rec, a.rec_bytes), make_rsrc(a.meta, a.meta_bytes)};
 
     uint4 st = make_uint4(0, 0, 0, 0);
@@ -239,6 +281,34 @@ __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint
     LogPos lp{tile * 1024u, 256u, tile * 1024u, 64u};   // codes / records this tile has appended to its logs so far
     constexpr int kPrefetch = PrefetchOf<PAIR>::value;
     const size_t gstep = (size_t)kPrefetch * a.stride;
+#if MI355_K1_DESC
+    if (FAST) {
+        uint32_t voff[kPrefetch];
+#pragma unroll
+        for (int d = 0; d < kPrefetch; d++) voff[d] = byte_off + (uint32_t)d * (uint32_t)a.stride;   // launch_diff_pack: (kPrefetch - 1) * stride + n < 2^32
+        const uint8_t *cb = a.cur, *pb = a.prev;
+        int64_t left = (int64_t)(T - 1) * (int64_t)a.stride + (int64_t)a.n;   // bytes from the group's first frame to the end of the batch's last frame
+        auto desc = [&](const uint8_t *base) {
+            const uint32_t bytes = left <= 0 ? 0u : (left > 0xffffffffll ? 0xffffffffu : (uint32_t)left);
+            return make_rsrc(base, bytes);
+        };
+        ga.load_desc(desc(cb), desc(pb), voff);
+        for (int t0 = 0;;) {
+            cb += gstep; if (PAIR) pb += gstep; left -= (int64_t)gstep;
+            gb.load_desc(desc(cb), desc(pb), voff);
+            pack_group<PAIR, FAST, HIGH>(a, ga, t0, st, lp, tile, tc, lane, lg);
+            t0 += kPrefetch;
+            if (t0 >= T) break;
+            cb += gstep; if (PAIR) pb += gstep; left -= (int64_t)gstep;
+            ga.load_desc(desc(cb), desc(pb), voff);
+            pack_group<PAIR, FAST, HIGH>(a, gb, t0, st, lp, tile, tc, lane, lg);
+            t0 += kPrefetch;
+            if (t0 >= T) break;
+        }
+        if (!PAIR) *reinterpret_cast<uint4 *>(a.state + byte_off) = st;
+        return;
+    }
+#endif
     const uint8_t *cur_last = a.cur + (size_t)(T - 1) * a.stride, *prev_last = PAIR ? a.prev + (size_t)(T - 1) * a.stride : nullptr;
     const uint8_t *cp = a.cur, *pp = a.prev;   // frame t0 + kPrefetch, the next group to request
     ga.load(a, byte_off, 0, valid, cp, pp, cur_last, prev_last);
@@ -263,6 +333,9 @@ __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint
 
 template <bool PAIR, bool ALIGNED, bool HIGH>
 __global__ __launch_bounds__(256) void k_diff_pack(const PackArgs a) {
+#if MI355_K1PRIO
+    __builtin_amdgcn_s_setprio(MI355_K1PRIO);
+#endif
     const int lane = threadIdx.x & 63;
     // one tile per wave when the grid covers the frame (the default); a smaller grid walks the tiles with its stride
     // (pipelined batches leave wave slots to the expansion of the batch before, core.hip)
@@ -447,14 +520,23 @@ hipError_t launch_scan(const uint4 *meta, uint32_t *roff, uint32_t *totals, uint
 }
 
 // ---- expand: codes + records -> packed frame-major (xs, diff) ------------------------------------------
-// grid = (ceil(W/16) rounded up to a multiple of 8, T), block = 64: one wave owns 16 consecutive tiles of
-// ONE frame, i.e. one contiguous range of that frame's output.  The wave loads the meta words of its whole
-// 64-tile group (the scan kernel gives the bytes in front of the group, the wave adds those in front of
-// its own 16 tiles) and keeps the per-tile facts in registers (ds_bpermute).  A small LDS table maps
-// "candidate r of the wave" to its tile; candidates are taken 64 at a time, four rounds to a pass: the codes
-// of a pass are requested together, then the records of its multi-byte lanes, then everything is staged in
-// LDS in output order (entry offsets from one DPP scan per round) and leaves with coalesced stores.
-// A code with one flagged byte IS its entry; only multi-byte lanes walk the bits of their map.  No barriers.
+// grid = (ceil(W/16), T) single-wave workgroups: a wave owns one ITEM = 16 consecutive tiles of ONE frame, i.e. one
+// contiguous range of that frame's output (the scan kernel gives the entries in front of it).  Two ways through an item:
+//   * the pair path (expand_pairs): items whose neighbouring tiles 2r, 2r + 1 have at most 64 candidates together,
+//     whose entries fit the LDS stage at once and which have at most 128 lanes with two or more flagged bytes -- all
+//     items of a webcam-like frame outside dense regions.  Round r expands tiles 2r and 2r + 1: the candidates of the
+//     first in lanes 0 .. nc - 1, those of the second behind them, so a lane finds its tile with one compare.  The 8
+//     code loads of the item are requested together straight after the meta words; the entry offsets of all rounds come
+//     from eight independent DPP scans in one block of straight code; a code with one flagged byte IS its entry and is
+//     staged at once; lanes with more bytes are only QUEUED (8 bytes in LDS: record index, map, stage index, source)
+//     and expanded 64 at a time by all lanes afterwards -- one record load and one bit walk per item;
+//   * the tile path (expand_tiles): everything else (dense regions, scene changes, synthetic worst cases) -- one
+//     tile per round with the whole wave, the stage flushed whenever the next tile would not fit; a tile with all of
+//     its 1024 bytes flagged bypasses the stage: its 64 records ARE the difference bytes, the indices are consecutive.
+// Round 3's expander packed the candidates of all 16 tiles densely into rounds of 64 and needed a table, a
+// running-maximum scan and a second table per round to find a candidate's tile again (~1150 instructions per item of
+// the 1080p stream, 0.144 ms per batch; the kernel is bound by what its waves issue -- profiles/r04c, r04f).
+// No barriers; 5 KB of LDS and at most 64 VGPRs: 32 waves per CU, the kernel lives on its occupancy.
 //
 // WIRE: the entries leave in the sender's byte stream instead (server/src/threads.cpp:227-229): frame t
 // is {u32 n, i32 xs[n], u8 diff[n]} at byte 4t + 5*offsets[t] of a.wire, so index and payload sections
@@ -493,9 +575,6 @@ __device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint32_
         xsp = (uint8_t *)(a.out_xs + d);
         dfp = a.out_diff + d;
     }
-#if MI355_XABLATE == 4
-    if (xs0 != 0xfffffff0u) n = 0;
-#endif
     const uint32_t n4 = n >> 2;
     for (uint32_t k = lane; k < n4; k += 64u) {
         const uint4 q = *reinterpret_cast<const uint4 *>(stage + 4 * k);
@@ -514,45 +593,34 @@ __device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint32_
     }
 }
 
-#ifndef MI355_XROUNDS
-#define MI355_XROUNDS 3
-#endif
 #ifndef MI355_XPRIO
 #define MI355_XPRIO 2
 #endif
-// Ablation builds of the expander (tools/ab_build.sh, never shipped): 1 = prologue only (meta, scans), 2 = + table and
-// code loads, 3 = + record loads, 4 = + staging in LDS but no output stores.  0 = the product.
-#ifndef MI355_XABLATE
-#define MI355_XABLATE 0
+// Timing builds of the expander (tools/ab_build.sh, never shipped; outputs wrong by design): 1 = prologue only,
+// 2 = + code loads, 3 = + rounds, 4 = + queued lanes but no output stores, 9 = nothing but the dispatch of the grid.
+#ifndef MI355_XFABLATE
+#define MI355_XFABLATE 0
 #endif
-constexpr uint32_t kWTiles = 16;             // tiles per single-wave workgroup: one DPP row of lanes, a quarter of a scan group
-constexpr uint32_t kWStage = 1024;     // entries staged per wave = the most a round of 64 candidates can hold
-constexpr int kXRounds = MI355_XROUNDS;      // rounds of 64 candidates whose loads are requested together
+// Diagnostic build (-DMI355_XSTAMP=1, tools/ab_build.sh, never shipped): every wave of k_expand stamps s_memtime at
+// the ends of its phases into a buffer of their own; launch_expand prints the average wave-cycles per phase.
+#ifndef MI355_XSTAMP
+#define MI355_XSTAMP 0
+#endif
+#if MI355_XSTAMP
+#define XSTAMP(k) do { __builtin_amdgcn_s_waitcnt(0xC07F); g_stamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ uint64_t *g_stamp_buf;
+#else
+#define XSTAMP(k) do { } while (0)
+#endif
+constexpr uint32_t kWTiles = 16;             // tiles per item: one DPP row of lanes, a quarter of a scan group
+constexpr uint32_t kWStage = 1024;           // entries of the LDS stage = the most one tile can hold
+constexpr uint32_t kFList = 128;             // most multi-byte lanes of an item on the pair path (queued in 1 KiB of LDS)
+constexpr uint32_t kFStage = kWStage;        // most entries of an item on the pair path (10 bits of a queued lane's word)
 #ifndef MI355_XLIGHT
 #define MI355_XLIGHT 4
 #endif
 constexpr uint32_t kXLight = MI355_XLIGHT;   // lanes with more flagged bytes than this are expanded by 16 lanes
-constexpr int kXHeavyMax = 12;               // ... unless a round of 64 candidates holds more of them than this
-
-// What a wave needs before it can start on its item (frame t, tiles 16 sub .. 16 sub + 15).
-struct ItemPro {
-    uint4 m;          // lane L < 16: meta word of tile 16 sub + L
-    uint32_t off_t;   // entries of the frames before t
-    uint32_t roff;    // entries of frame t before the item's tiles
-    uint32_t n_t;     // WIRE: entries of frame t
-};
-
-template <bool WIRE>
-__device__ __forceinline__ ItemPro load_item(const ExpandArgs &a, uint32_t t, uint32_t sub, uint32_t ngroups, uint32_t lane) {
-    ItemPro p;
-    const uint32_t tile = sub * kWTiles + lane;
-    p.m = make_uint4(0, 0, 0, 0);
-    if (lane < kWTiles && tile < a.ntiles) p.m = a.meta[(size_t)t * a.ntiles + tile];
-    p.off_t = a.offsets[t];
-    p.roff = a.roff[(size_t)t * ngroups * 4u + sub];
-    p.n_t = WIRE ? a.offsets[t + 1] - p.off_t : 0u;
-    return p;
-}
+constexpr int kXHeavyMax = 12;               // ... unless a round of 64 lanes holds more of them than this
 
 // inclusive scan inside the first 16 lanes (one DPP row)
 __device__ __forceinline__ int row_inclusive_scan(int v) {
@@ -563,201 +631,352 @@ __device__ __forceinline__ int row_inclusive_scan(int v) {
     return v;
 }
 
-// grid = (ceil(W/16), T) single-wave workgroups: one item each (the hardware's dispatcher balances the items;
-// a persistent grid walking them with a fixed stride was measured 0.05 ms slower per batch: the slowest wave's
-// share decides, and the waves fall into step).  8 waves per SIMD (the register budget is set for that): the
-// kernel is a chain of short dependent steps, what hides them is the number of waves.
+// The bit walk: every lane with m16 != 0 turns its record (16 masked difference bytes) into entries
+// stage[e], stage[e + 1], ... = (src16 + byte) << 8 | difference.  Lanes with up to kXLight flagged bytes walk
+// their bits; lanes with more (object edges among isolated bytes) would make the whole wave walk theirs, so they are
+// expanded by 16 lanes each, four records at a time through ds_bpermute -- unless the wave holds more than kXHeavyMax
+// of them (dense tiles): then everybody walks, all lanes busy for as many steps as the fullest lane has bytes.
+__device__ __forceinline__ void walk_records(uint32_t m16, uint32_t e, uint32_t src16, uint4 rec, uint32_t *stage, uint32_t lane) {
+    const uint32_t cnt = (uint32_t)__builtin_popcount(m16);
+    uint64_t heavy = __ballot(cnt > kXLight);
+    const uint32_t light_max = __builtin_popcountll(heavy) > kXHeavyMax ? 16u : kXLight;
+    if (light_max == 16u) heavy = 0;
+    if (cnt != 0u && cnt <= light_max) {
+        uint32_t mm = m16, ee = e;
+        do {
+            const int b = __builtin_ctz(mm);
+            mm &= mm - 1;
+            const uint32_t dw = b < 8 ? (b < 4 ? rec.x : rec.y) : (b < 12 ? rec.z : rec.w);
+            stage[ee] = ((src16 + (uint32_t)b) << 8) | ((dw >> (8 * (b & 3))) & 0xffu);   // kernels.cu:314-315
+            ++ee;
+        } while (mm);
+    }
+    if (heavy) {   // wave-uniform
+        const uint32_t g = lane >> 4, b = lane & 15u;
+        uint64_t h = heavy;
+        do {
+            // the lanes of (up to) four heavy records; a missing one repeats the first and is masked out
+            const int l0 = __builtin_ctzll(h);
+            h &= h - 1;
+            const int l1 = h ? __builtin_ctzll(h) : -1;
+            h = h ? h & (h - 1) : 0;
+            const int l2 = h ? __builtin_ctzll(h) : -1;
+            h = h ? h & (h - 1) : 0;
+            const int l3 = h ? __builtin_ctzll(h) : -1;
+            h = h ? h & (h - 1) : 0;
+            const int srcl = g == 0 ? l0 : (g == 1 ? l1 : (g == 2 ? l2 : l3));
+            const int sa = (srcl < 0 ? l0 : srcl) * 4;
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)rec.x);
+            const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)rec.y);
+            const uint32_t r2 = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)rec.z);
+            const uint32_t r3 = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)rec.w);
+            const uint32_t hm = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)m16);
+            const uint32_t he = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)e);
+            const uint32_t hs = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)src16);
+            if (srcl >= 0 && ((hm >> b) & 1u)) {
+                const uint32_t pos = he + (uint32_t)__builtin_popcount(hm & ((1u << b) - 1u));
+                const uint32_t dw = b < 8 ? (b < 4 ? r0 : r1) : (b < 12 ? r2 : r3);
+                stage[pos] = ((hs + b) << 8) | ((dw >> (8 * (b & 3))) & 0xffu);
+            }
+        } while (h);
+    }
+}
+
+// The pair path.  mx / my / mz hold, in lane L < 16, tile L's {byte offset of its first code, byte offset of its first
+// record, entries of the item before the tile | candidates << 16}.  What a round needs of its two tiles is wave-uniform
+// and is read into SGPRs (v_readlane) right where it is used: through LDS the same facts cost a write, a read and a
+// wait per round (~150 cycles each; a third of the wave's lifetime, profiles/r04l_expand_stamps.log).
+// Fills stage[0 .. entries of the item) in output order.
+__device__ __forceinline__ void expand_pairs(const ExpandArgs &a, uint32_t mx, uint32_t my, uint32_t mz, uint2 *list, uint32_t *stage,
+                                             uint32_t lane
+#if MI355_XSTAMP
+                                             , uint64_t *g_stamp
+#endif
+                                             ) {
+    const __amdgpu_buffer_rsrc_t codes = make_rsrc(a.codes, a.codes_bytes), recs = make_rsrc(a.rec, a.rec_bytes);
+    // round r: the candidates of tile 2r in lanes 0 .. nc - 1, those of tile 2r + 1 behind them (together at most 64)
+    uint32_t code[kWTiles / 2];
+    const uint32_t lane4 = lane * 4u;
+#pragma unroll
+    for (uint32_t r = 0; r < kWTiles / 2; r++) {
+        const uint32_t nc_a = (uint32_t)__builtin_amdgcn_readlane((int)mz, 2 * r) >> 16, nc_b = (uint32_t)__builtin_amdgcn_readlane((int)mz, 2 * r + 1) >> 16;
+        const uint32_t pc_a = (uint32_t)__builtin_amdgcn_readlane((int)mx, 2 * r), pc_b = (uint32_t)__builtin_amdgcn_readlane((int)mx, 2 * r + 1);
+        const uint32_t off = lane >= nc_a ? lane4 + (pc_b - 4u * nc_a) : lane4 + pc_a;
+        code[r] = __builtin_amdgcn_raw_buffer_load_b32(codes, lane < nc_a + nc_b ? off : kOOB, 0, 0);   // a lane without a candidate reads 0
+    }
+#if MI355_XFABLATE == 2
+    { uint32_t acc = 0;
+#pragma unroll
+      for (uint32_t r = 0; r < kWTiles / 2; r++) acc ^= code[r];
+      if (acc == 0xfffffff0u) stage[0] = acc; }
+    return;
+#endif
+    __builtin_amdgcn_sched_barrier(0);   // all eight requests leave before anything waits for the first
+#if MI355_XSTAMP
+    XSTAMP(2);                                    // code loads issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    XSTAMP(3);                                    // codes here
+#endif
+    // entry offsets of all rounds first: eight independent DPP scans in one block of straight code fill each other's
+    // wait states (a scan alone is 7 dependent steps with 2 idle cycles between them)
+    uint32_t ent[kWTiles / 2];
+#pragma unroll
+    for (uint32_t r = 0; r < kWTiles / 2; r++) {
+        const uint32_t cnt = (uint32_t)__builtin_popcount(code[r] & 0xffffu);
+        ent[r] = (uint32_t)wave_inclusive_scan((int)cnt) - cnt;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    XSTAMP(4);                                    // scans done
+    // lanes with two or more flagged bytes are queued first, so that their records are on the way while the lanes
+    // with one byte stage their entries
+    uint32_t tail = 0;   // queued lanes (wave-uniform)
+#pragma unroll
+    for (uint32_t r = 0; r < kWTiles / 2; r++) {
+        const uint32_t c = code[r];
+        const uint32_t m16 = c & 0xffffu;
+        const bool multi = (m16 & (m16 - 1u)) != 0u;
+        const uint64_t bm = __ballot(multi);
+        if (bm) {   // wave-uniform
+            const uint32_t za = (uint32_t)__builtin_amdgcn_readlane((int)mz, 2 * r);
+            const uint32_t pm_a = (uint32_t)__builtin_amdgcn_readlane((int)my, 2 * r) >> 4, pm_b = (uint32_t)__builtin_amdgcn_readlane((int)my, 2 * r + 1) >> 4;
+            const bool second = lane >= (za >> 16);
+            const uint32_t e = (za & 0xffffu) + ent[r];
+            const uint32_t val = (c >> 16) & 0xffu;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+            if (multi)   // {record index | tile << 28,  map | stage index << 16 | lane << 26}
+                list[tail + rank] = make_uint2((second ? pm_b + val + ((2u * r + 1u) << 28) : pm_a + val + ((2u * r) << 28)),
+                                               m16 | (e << 16) | ((c & 0x3f000000u) << 2));
+            tail += (uint32_t)__builtin_popcountll(bm);
+        }
+    }
+    lds_handoff();
+    // the first 64 queued lanes' records (an item rarely queues more)
+    const uint2 w0 = list[lane];
+    const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(recs, lane < tail ? (w0.x << 4) : kOOB, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    XSTAMP(5);                                    // queued, records requested
+#pragma unroll
+    for (uint32_t r = 0; r < kWTiles / 2; r++) {
+        const uint32_t c = code[r];
+        const uint32_t m16 = c & 0xffffu;
+        const uint32_t za = (uint32_t)__builtin_amdgcn_readlane((int)mz, 2 * r);
+        const uint32_t e = (za & 0xffffu) + ent[r];   // index in the stage = in the item (tile 2r + 1 follows tile 2r)
+        // first byte of the lane relative to the item: (tile << 10) + lane of the pack kernel * 16
+        const uint32_t src16 = ((c >> 20) & 0x3f0u) + (lane >= (za >> 16) ? (2u * r + 1u) << 10 : (2u * r) << 10);
+        if (m16 != 0u && (m16 & (m16 - 1u)) == 0u)
+            stage[e] = ((src16 + (uint32_t)__builtin_ctz(m16)) << 8) | ((c >> 16) & 0xffu);   // kernels.cu:314-315
+    }
+#if MI355_XFABLATE == 3
+    return;
+#endif
+#if MI355_XSTAMP
+    XSTAMP(6);                                    // one-byte lanes staged
+#endif
+    walk_records(lane < tail ? (w0.y & 0xffffu) : 0u, (w0.y >> 16) & 0x3ffu, ((w0.x >> 28) << 10) | ((w0.y >> 26) << 4),
+                 make_uint4(q0.x, q0.y, q0.z, q0.w), stage, lane);
+    for (uint32_t head = 64u; head < tail; head += 64u) {   // the rest, 64 at a time
+        const bool on = head + lane < tail;
+        const uint2 w = list[min(head + lane, kFList - 1u)];
+        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(recs, on ? (w.x << 4) : kOOB, 0, 0);
+        walk_records(on ? (w.y & 0xffffu) : 0u, (w.y >> 16) & 0x3ffu, ((w.x >> 28) << 10) | ((w.y >> 26) << 4),
+                     make_uint4(q.x, q.y, q.z, q.w), stage, lane);
+    }
+}
+
+// The tile path.  tinfo[i] = {byte offset of the first code, of the first record, flagged bytes, candidates} of the
+// item's tile i; xs0 = byte index of the item's first byte, dst0 = entries of the batch before the item.
+// A tile needs two dependent loads (its codes, then the records its codes name); the loop keeps the codes two tiles
+// ahead and the records one tile ahead of the tile it expands, so a wave waits for memory once per item, not twice per
+// tile (an item of a dense region is 16 such tiles: without the look-ahead it took ~50 us, and a scene change late in
+// a batch held the whole grid up).
+template <bool WIRE>
+__device__ __forceinline__ void expand_tiles(const ExpandArgs &a, const uint4 *tinfo, uint32_t *stage, uint32_t lane, uint32_t xs0,
+                                             uint32_t dst0, uint8_t *w_xs, uint8_t *w_df, size_t w_room) {
+    const __amdgpu_buffer_rsrc_t codes = make_rsrc(a.codes, a.codes_bytes), recs = make_rsrc(a.rec, a.rec_bytes);
+    // loads beyond the item (i >= 16) or without a candidate carry an offset outside the buffer: they return 0 and read nothing
+    auto load_code = [&](uint32_t i) {
+        const uint4 ti = tinfo[i & (kWTiles - 1u)];
+        return __builtin_amdgcn_raw_buffer_load_b32(codes, (i < kWTiles && lane < ti.w) ? ti.x + 4u * lane : kOOB, 0, 0);
+    };
+    auto load_rec = [&](uint32_t i, uint32_t c) {
+        const uint4 ti = tinfo[i & (kWTiles - 1u)];
+        const uint32_t m16 = c & 0xffffu;
+        // a tile with all bytes flagged: record `lane`; otherwise the record of a lane with two or more flagged bytes
+        const uint32_t off = ti.z == kTileBytes ? ti.y + 16u * lane : ((m16 & (m16 - 1u)) ? ti.y + 16u * ((c >> 16) & 0xffu) : kOOB);
+        return __builtin_amdgcn_raw_buffer_load_b128(recs, i < kWTiles ? off : kOOB, 0, 0);
+    };
+    uint32_t carry = 0, flushed = 0;   // entries of the item expanded so far / already stored (wave-uniform)
+    uint32_t c0 = load_code(0), c1 = load_code(1);
+    u32x4 r0 = load_rec(0, c0);
+#pragma unroll 1
+    for (uint32_t i = 0; i < kWTiles; i++) {
+        const uint32_t c2 = load_code(i + 2u);
+        const u32x4 r1 = load_rec(i + 1u, c1);
+        const uint4 ti = tinfo[i];
+        const uint32_t nc = (uint32_t)__builtin_amdgcn_readfirstlane((int)ti.w), bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)ti.z);
+        if (nc != 0u) {
+            const bool full = bytes == kTileBytes;   // every byte of the tile flagged: its 64 records are the difference bytes
+            if (full || carry - flushed + bytes > kWStage) {   // make room (a full tile goes straight out: empty the stage first)
+                lds_handoff();
+                flush_entries<WIRE>(a, stage, flushed, carry - flushed, xs0, dst0, w_xs, w_df, w_room);
+                lds_handoff();   // the stage is rewritten from its start
+                flushed = carry;
+            }
+            if (full && (WIRE ? w_room != 0 : (size_t)dst0 + carry + kTileBytes <= a.capacity)) {
+                // all 64 lanes carry 16 bytes: record `lane` of the tile holds the differences of its bytes 16 lane .. 16 lane + 15
+                // (one wave-contiguous KiB); the 1024 indices are consecutive and leave as four wave-contiguous KiB
+                uint8_t *xsp = WIRE ? w_xs + 4 * (size_t)carry : (uint8_t *)(a.out_xs + (size_t)dst0 + carry);
+                uint8_t *dfp = WIRE ? w_df + carry : a.out_diff + (size_t)dst0 + carry;
+                const uint32_t x = xs0 + (i << 10) + 4u * lane;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++)
+                    *reinterpret_cast<U32x4A1 *>(xsp + 1024 * k + 16 * lane) = U32x4A1{x + 256 * k, x + 256 * k + 1, x + 256 * k + 2, x + 256 * k + 3};
+                *reinterpret_cast<U32x4A1 *>(dfp + 16 * lane) = U32x4A1{r0.x, r0.y, r0.z, r0.w};
+                flushed = carry + kTileBytes;
+            } else {
+                const uint32_t m16 = c0 & 0xffffu;
+                const uint32_t cnt = (uint32_t)__builtin_popcount(m16);
+                const uint32_t e = carry - flushed + (uint32_t)wave_inclusive_scan((int)cnt) - cnt;
+                const uint32_t src16 = (i << 10) + ((c0 >> 20) & 0x3f0u);
+                if (cnt == 1u) stage[e] = ((src16 + (uint32_t)__builtin_ctz(m16)) << 8) | ((c0 >> 16) & 0xffu);   // kernels.cu:314-315
+                const bool multi = cnt > 1u;
+                if (__ballot(multi)) walk_records(multi ? m16 : 0u, e, src16, make_uint4(r0.x, r0.y, r0.z, r0.w), stage, lane);   // wave-uniform
+            }
+            carry += bytes;
+        }
+        c0 = c1; c1 = c2; r0 = r1;
+    }
+    lds_handoff();
+    flush_entries<WIRE>(a, stage, flushed, carry - flushed, xs0, dst0, w_xs, w_df, w_room);
+}
+
 template <bool WIRE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_expand(const ExpandArgs a) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[kWTiles * 64];   // candidate rank of the wave -> tile + 1 at the first candidate of every tile, 0 elsewhere
-    __shared__ uint2 s_tinfo[kWTiles];            // per tile: {byte offset of its candidate 0 in the code log - 4 * (candidates before the tile), byte offset of its first record}
-    __shared__ __attribute__((aligned(16))) uint32_t s_stage[kWStage];   // (byte index relative to the wave's first tile) << 8 | difference
+    __shared__ __attribute__((aligned(16))) uint2 s_list[kFList];         // pair path: the item's queued (multi-byte) lanes; tile path: the 16 tiles' facts
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[kWStage];    // (byte index relative to the item's first tile) << 8 | difference
+    // 5120 bytes of LDS: 32 single-wave workgroups per CU
 #if MI355_XPRIO
     // beside the next batch's pack kernel (pipelined batches) these short, latency-bound waves must not queue for
     // issue slots behind the older, issue-hungry pack waves
     __builtin_amdgcn_s_setprio(MI355_XPRIO);
 #endif
     const uint32_t lane = threadIdx.x;
-    const uint32_t ngroups = (a.ntiles + kXTiles - 1) / kXTiles;
+#if MI355_XFABLATE == 9
+    return;
+#endif
+#if MI355_XSTAMP
+    uint64_t g_stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    XSTAMP(0);                                    // wave started
+#endif
     const uint32_t t = blockIdx.y, sub = blockIdx.x;
-    if (sub * kWTiles >= a.ntiles) return;   // grid.x is padded to a multiple of 8 (see launch_expand)
-    const ItemPro cur = load_item<WIRE>(a, t, sub, ngroups, lane);
-    {
-        const uint32_t tile0 = sub * kWTiles;
-        const uint4 m = cur.m;   // {code offset, record offset, flagged bytes, candidates | multi << 16}
-        size_t head = 0;
-        if (WIRE) {
-            head = 4 * (size_t)t + 5 * (size_t)cur.off_t;
-            if (sub == 0 && lane == 0 && head + 4 <= a.capacity) store_u32_unaligned(a.wire + head, cur.n_t);
-        }
-        // lane L < 16 <-> tile L of the item
-        const uint32_t nc = m.w & 0xffffu;   // 0 in lanes >= 16
-        const uint32_t rincl = (uint32_t)row_inclusive_scan((int)nc);
-        const uint32_t nrec = (uint32_t)__builtin_amdgcn_readlane((int)rincl, (int)kWTiles - 1);
-        if (nrec != 0) {
-            const uint32_t dst0 = cur.off_t + cur.roff;   // < 2^32: the batch total is below 2^32
-            const uint32_t rexcl = rincl - nc;                     // candidates of this wave before the lane's tile
-            uint8_t *w_xs = nullptr, *w_df = nullptr;
-            size_t w_room = 0;
-            if (WIRE) {
-                const size_t end = head + 4 + 5 * (size_t)cur.n_t;
-                const uint32_t seg = dst0 - cur.off_t;
-                w_xs = a.wire + head + 4 + 4 * (size_t)seg;
-                w_df = a.wire + head + 4 + 4 * (size_t)cur.n_t + seg;
-                w_room = end <= a.capacity ? (size_t)cur.n_t : 0;
-            }
-#if MI355_XABLATE == 1
-            if (dst0 == 0xfffffff0u) a.out_xs[0] = (int32_t)nrec;
-#else
-            if (lane < kWTiles) s_tinfo[lane] = make_uint2(m.x - 4u * rexcl, m.y);
-            // which tile candidate r of the wave belongs to: tile i owns ranks rexcl_i .. rexcl_i + nc_i - 1.  Only the
-            // HEAD of every tile's range is marked (tile + 1 at rank rexcl_i, zeros elsewhere); a running maximum over
-            // the candidates of a round (one DPP scan, the maximum so far carried from round to round) turns the heads
-            // into "my tile" -- instead of a loop over the 16 tiles writing every rank
-            reinterpret_cast<uint4 *>(s_tile)[lane] = make_uint4(0, 0, 0, 0);
-            lds_handoff();
-            if (lane < kWTiles && nc != 0u) s_tile[rexcl] = (uint8_t)(lane + 1u);
-            lds_handoff();   // the tables are read by other lanes than the ones that wrote them
-            uint32_t tile_carry = 0;   // highest head seen in the rounds before (wave-uniform)
-            const uint32_t xs_base = tile0 * kTileBytes;
-            uint32_t carry = 0, flushed = 0;   // entries emitted / already stored
-            for (uint32_t base = 0; base < nrec; base += 64u * kXRounds) {
-                // (1) the codes of the pass: table reads, then loads, back to back (indices clamped, not masked)
-                uint32_t code[kXRounds], src16[kXRounds], pm[kXRounds];
-                {
-                    uint32_t rr[kXRounds], ti[kXRounds];
-                    uint2 inf[kXRounds];
-#pragma unroll
-                    for (int k = 0; k < kXRounds; k++) {
-                        rr[k] = min(base + 64u * (uint32_t)k + lane, nrec - 1u);
-                        ti[k] = s_tile[rr[k]];
-                    }
-#pragma unroll
-                    for (int k = 0; k < kXRounds; k++) {
-                        const uint32_t run = max(wave_inclusive_max_scan(ti[k]), tile_carry);   // >= 1: candidate 0 is a head
-                        tile_carry = (uint32_t)__builtin_amdgcn_readlane((int)run, 63);
-                        ti[k] = run - 1u;
-                    }
-#pragma unroll
-                    for (int k = 0; k < kXRounds; k++) inf[k] = s_tinfo[ti[k]];
-#pragma unroll
-                    for (int k = 0; k < kXRounds; k++) {
-                        code[k] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(a.codes) + (inf[k].x + 4u * rr[k]));
-                        pm[k] = inf[k].y;
-                        src16[k] = ti[k] * kTileBytes;
-                    }
-#pragma unroll
-                    for (int k = 0; k < kXRounds; k++) {
-                        if (base + 64u * (uint32_t)k + lane >= nrec) code[k] = 0;   // also whole rounds beyond the wave's candidates
-                        src16[k] += ((code[k] >> 24) & 63u) * 16u;                  // first byte of the lane, relative to the wave's first tile
-                    }
-                }
-#if MI355_XABLATE == 2
-                { uint32_t acc = 0;
-#pragma unroll
-                  for (int k = 0; k < kXRounds; k++) acc ^= code[k];
-                  if (acc == 0xfffffff0u) a.out_xs[0] = (int32_t)acc; }
-                continue;
-#endif
-                // (2) the records of its multi-byte lanes
-                uint4 rec[kXRounds];
-#pragma unroll
-                for (int k = 0; k < kXRounds; k++) {
-                    const uint32_t m16 = code[k] & 0xffffu;
-                    rec[k] = make_uint4(0, 0, 0, 0);
-                    if (m16 & (m16 - 1u))
-                        rec[k] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(a.rec) + (pm[k] + ((code[k] >> 16) & 0xffu) * 16u));
-                }
-#if MI355_XABLATE == 3
-                { uint32_t acc = 0;
-#pragma unroll
-                  for (int k = 0; k < kXRounds; k++) acc ^= code[k] ^ rec[k].x ^ rec[k].y ^ rec[k].z ^ rec[k].w;
-                  if (acc == 0xfffffff0u) a.out_xs[0] = (int32_t)acc; }
-                continue;
-#endif
-                // (3) stage the entries in output order
-#pragma unroll
-                for (int k = 0; k < kXRounds; k++) {
-                    if (base + 64u * (uint32_t)k >= nrec) break;   // wave-uniform
-                    const uint32_t m16 = code[k] & 0xffffu;
-                    const uint32_t cnt = (uint32_t)__builtin_popcount(m16);
-                    const uint32_t incl = (uint32_t)wave_inclusive_scan((int)cnt);
-                    const uint32_t round_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    if (carry - flushed + round_total > kWStage) {   // wave-uniform: make room
-                        lds_handoff();
-                        flush_entries<WIRE>(a, s_stage, flushed, carry - flushed, xs_base, dst0, w_xs, w_df, w_room);
-                        lds_handoff();   // the stage is rewritten from its start
-                        flushed = carry;
-                    }
-                    const uint32_t e = carry - flushed + incl - cnt;        // index in the LDS stage
-                    carry += round_total;
-                    // lanes with more than kXLight flagged bytes (object edges among isolated bytes) would make the whole
-                    // wave walk their bits: they are expanded by 16 lanes each afterwards, four at a time
-                    // -- unless the round holds more than kXHeavyMax of them (dense frames): then everybody walks, all
-                    // lanes busy for as many steps as the fullest lane has bytes
-                    uint64_t heavy = __ballot(cnt > kXLight);
-                    const uint32_t light_max = __builtin_popcountll(heavy) > kXHeavyMax ? 16u : kXLight;
-                    if (light_max == 16u) heavy = 0;
-                    if (cnt == 1u) {
-                        s_stage[e] = ((src16[k] + (uint32_t)__builtin_ctz(m16)) << 8) | ((code[k] >> 16) & 0xffu);   // kernels.cu:314-315
-                    } else if (cnt > 1u && cnt <= light_max) {
-                        uint32_t mm = m16, ee = e;
-                        do {
-                            const int b = __builtin_ctz(mm);
-                            mm &= mm - 1;
-                            const uint32_t dw = b < 8 ? (b < 4 ? rec[k].x : rec[k].y) : (b < 12 ? rec[k].z : rec[k].w);
-                            s_stage[ee] = ((src16[k] + (uint32_t)b) << 8) | ((dw >> (8 * (b & 3))) & 0xffu);
-                            ++ee;
-                        } while (mm);
-                    }
-                    if (heavy) {   // wave-uniform
-                        const uint32_t g = lane >> 4, b = lane & 15u;
-                        uint64_t h = heavy;
-                        do {
-                            // the lanes of (up to) four heavy records; a missing one repeats the first and is masked out
-                            const int l0 = __builtin_ctzll(h);
-                            h &= h - 1;
-                            const int l1 = h ? __builtin_ctzll(h) : -1;
-                            h = h ? h & (h - 1) : 0;
-                            const int l2 = h ? __builtin_ctzll(h) : -1;
-                            h = h ? h & (h - 1) : 0;
-                            const int l3 = h ? __builtin_ctzll(h) : -1;
-                            h = h ? h & (h - 1) : 0;
-                            const int srcl = g == 0 ? l0 : (g == 1 ? l1 : (g == 2 ? l2 : l3));
-                            const int sa = (srcl < 0 ? l0 : srcl) * 4;
-                            const uint32_t r0 = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)rec[k].x);
-                            const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)rec[k].y);
-                            const uint32_t r2 = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)rec[k].z);
-                            const uint32_t r3 = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)rec[k].w);
-                            const uint32_t hm = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)m16);
-                            const uint32_t he = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)e);
-                            const uint32_t hs = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)src16[k]);
-                            if (srcl >= 0 && ((hm >> b) & 1u)) {
-                                const uint32_t pos = he + (uint32_t)__builtin_popcount(hm & ((1u << b) - 1u));
-                                const uint32_t dw = b < 8 ? (b < 4 ? r0 : r1) : (b < 12 ? r2 : r3);
-                                s_stage[pos] = ((hs + b) << 8) | ((dw >> (8 * (b & 3))) & 0xffu);
-                            }
-                        } while (h);
-                    }
-                }
-            }
-            lds_handoff();
-            flush_entries<WIRE>(a, s_stage, flushed, carry - flushed, xs_base, dst0, w_xs, w_df, w_room);
-#endif
-        }
+    const uint32_t ngroups = (a.ntiles + kXTiles - 1) / kXTiles;
+    // lane L < 16: meta word of tile 16 sub + L = {code offset, record offset, flagged bytes, candidates | multi-byte
+    // lanes << 16}; the other lanes (and tiles beyond the frame) read nothing and get zeros
+    const uint32_t tile = sub * kWTiles + lane;
+    const __amdgpu_buffer_rsrc_t metas = make_rsrc(a.meta + (size_t)t * a.ntiles, a.ntiles * 16u);
+    const u32x4 mq = __builtin_amdgcn_raw_buffer_load_b128(metas, lane < kWTiles ? tile * 16u : kOOB, 0, 0);
+    const uint32_t off_t = a.offsets[t];                                        // entries of the frames before t
+    const uint32_t roff = a.roff[(size_t)t * ngroups * 4u + sub];               // entries of frame t before the item's tiles
+    const uint32_t n_t = WIRE ? a.offsets[t + 1] - off_t : 0u;                  // entries of frame t
+    const uint4 m = make_uint4(mq.x, mq.y, mq.z, mq.w);
+    size_t head = 0;
+    if (WIRE) {
+        head = 4 * (size_t)t + 5 * (size_t)off_t;
+        if (sub == 0 && lane == 0 && head + 4 <= a.capacity) store_u32_unaligned(a.wire + head, n_t);
     }
+    const uint32_t nc = m.w & 0xffffu;   // 0 in lanes >= 16
+    // the item's entries before each of its tiles | its multi-byte lanes << 16, and their totals
+    const uint32_t both = m.z | (m.w & 0xffff0000u);
+    const uint32_t bincl = (uint32_t)row_inclusive_scan((int)both);
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)bincl, (int)kWTiles - 1);
+    const uint32_t nent = tot & 0xffffu;
+    if (nent == 0u) return;
+    const uint32_t dst0 = off_t + roff;   // < 2^32: the batch total is below 2^32
+    XSTAMP(1);                                    // meta words, offsets here
+    uint8_t *w_xs = nullptr, *w_df = nullptr;
+    size_t w_room = 0;
+    if (WIRE) {
+        const size_t wend = head + 4 + 5 * (size_t)n_t;
+        w_xs = a.wire + head + 4 + 4 * (size_t)roff;
+        w_df = a.wire + head + 4 + 4 * (size_t)n_t + roff;
+        w_room = wend <= a.capacity ? (size_t)n_t : 0;
+    }
+    const uint32_t xs0 = sub * kWTiles * kTileBytes;
+    // two neighbouring tiles share a round of 64 lanes; the even tile's lane learns the odd tile's facts
+    const uint32_t nc_b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nc, 0x101 /* row_shl:1 */, 0xf, 0xf, true);
+    const bool even = (lane & 1u) == 0u;
+    const bool pairs = __ballot(even && nc + nc_b > 64u) == 0 && nent <= kFStage && (tot >> 16) <= kFList;   // wave-uniform
+    if (!pairs) {
+        uint4 *const s_tinfo = reinterpret_cast<uint4 *>(s_list);
+        if (lane < kWTiles) s_tinfo[lane] = make_uint4(m.x, m.y, m.z, nc);
+        lds_handoff();
+        expand_tiles<WIRE>(a, s_tinfo, s_stage, lane, xs0, dst0, w_xs, w_df, w_room);
+        return;
+    }
+#if MI355_XFABLATE != 1
+    expand_pairs(a, m.x, m.y, ((bincl - both) & 0xffffu) | (nc << 16), s_list, s_stage, lane
+#if MI355_XSTAMP
+                 , g_stamp
+#endif
+                 );
+    lds_handoff();
+    XSTAMP(7);                                    // queued lanes expanded
+#if MI355_XFABLATE < 2
+    flush_entries<WIRE>(a, s_stage, 0u, nent, xs0, dst0, w_xs, w_df, w_room);
+#endif
+#endif
+#if MI355_XSTAMP
+    XSTAMP(8);                                    // stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    XSTAMP(9);                                    // stores done
+    if (lane == 0) {
+        uint64_t *o = g_stamp_buf + ((size_t)t * gridDim.x + sub) * 10;
+#pragma unroll
+        for (int k = 0; k < 10; k++) o[k] = g_stamp[k];
+    }
+#endif
 }
 
 hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s) {
     static_assert(kWTiles * 4u == kXTiles, "k_scan_groups writes four range prefixes per group");
-    // Workgroups go to the 8 XCDs round-robin by linear id: with grid.x a multiple of 8 the workgroups of one
-    // tile range land on the same XCD for every frame (the padding workgroups return at once).
-    const uint32_t gx = (a.ntiles + kWTiles - 1) / kWTiles;
-    const dim3 grid((gx + 7u) / 8u * 8u, nframes);
+    const dim3 grid((a.ntiles + kWTiles - 1) / kWTiles, nframes);
+#if MI355_XSTAMP
+    static uint64_t *buf = nullptr;
+    static size_t cap = 0;
+    const size_t words = (size_t)grid.x * grid.y * 10;
+    if (words > cap) {
+        if (buf) (void)hipFree(buf);
+        if (hipMalloc((void **)&buf, words * 8) != hipSuccess) return hipErrorOutOfMemory;
+        cap = words;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof buf);
+    }
+    (void)hipMemsetAsync(buf, 0, words * 8, s);
+#endif
     if (a.wire)
         hipLaunchKernelGGL(k_expand<true>, grid, dim3(64), 0, s, a);
     else
         hipLaunchKernelGGL(k_expand<false>, grid, dim3(64), 0, s, a);
+#if MI355_XSTAMP
+    static int calls = 0;
+    if (++calls == 8) {   // one steady-state launch
+        (void)hipStreamSynchronize(s);
+        std::vector<uint64_t> h(words);
+        (void)hipMemcpy(h.data(), buf, words * 8, hipMemcpyDeviceToHost);
+        double sum[10] = {0}; size_t n = 0; uint64_t first = ~0ull, last = 0;
+        for (size_t i = 0; i < words; i += 10) {
+            if (!h[i + 9]) continue;   // the tile path, or an empty item
+            for (int k = 1; k < 10; k++) sum[k] += (double)(h[i + k] - h[i + k - 1]);
+            first = h[i] < first ? h[i] : first; last = h[i + 9] > last ? h[i + 9] : last;
+            n++;
+        }
+        fprintf(stderr, "xstamp: %zu waves on the pair path, kernel span %.0f cycles; average wave-cycles per phase:\n", n, (double)(last - first));
+        const char *name[10] = {"", "start -> meta+offsets here", "-> code loads issued", "-> codes here", "-> scans done", "-> queued, records asked",
+                                "-> one-byte lanes staged", "-> queued lanes expanded", "-> stores issued", "-> stores done"};
+        double tot = 0;
+        for (int k = 1; k < 10; k++) { fprintf(stderr, "  %-28s %8.0f\n", name[k], sum[k] / n); tot += sum[k] / n; }
+        fprintf(stderr, "  %-28s %8.0f\n", "wave lifetime", tot);
+    }
+#endif
     return hipGetLastError();
 }
 

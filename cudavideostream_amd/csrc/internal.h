@@ -37,6 +37,8 @@ struct ExpandArgs {
     const uint32_t *roff;     // [T][4G] flagged bytes of the frame before each range of 16 tiles (G = ceil(W/64) groups)
     const uint32_t *offsets;  // [T+1]   exclusive scan of the frame totals
     uint32_t ntiles;
+    uint32_t codes_bytes;     // sizes of the two logs (the expander's buffer descriptors; both < 2^32)
+    uint32_t rec_bytes;
     int32_t *out_xs;
     uint8_t *out_diff;
     uint8_t *wire;            // != nullptr: write the sender's byte stream here instead of out_xs/out_diff

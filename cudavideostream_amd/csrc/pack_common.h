@@ -52,10 +52,25 @@ constexpr uint32_t kH = 0x80808080u, kL = 0x7f7f7f7fu;
 struct ThrConst {   // per-byte replicated constants of T' = T (T <= 127) or T - 128 (T >= 128: the HIGH form)
     uint32_t ca;    // 127 - T' : (x_l + ca) carries into bit 7  <=>  x_l >= T' + 1
     uint32_t cb;    // T'       : (x_l + cb) carries into bit 7  <=>  x_l >= 128 - T'
+    uint32_t h;     // 0x80808080 (kH), for the kernels that keep their constants in vector registers (vgpr_consts)
+    uint32_t w0, w1;   // v_dot4 weights that turn 0x80 flag bytes into 128 * (bit 0..3 / bit 4..7 of a byte map)
 };
 __host__ __device__ inline ThrConst make_thr(uint32_t thr /* 0..255 */) {
     const uint32_t t = thr & 127u;
-    return ThrConst{(127u - t) * 0x01010101u, t * 0x01010101u};
+    return ThrConst{(127u - t) * 0x01010101u, t * 0x01010101u, 0x80808080u, 0x08040201u, 0x80402010u};
+}
+
+// A wave-uniform constant as a VECTOR register.  On gfx950 a VALU instruction with a scalar-register operand issues in
+// ~4.4 cycles per wave64 against ~2.7 for the all-vector form (tools/ubench/issue_rate2.hip, profiles/r04n): the pack
+// kernel uses its three compare constants 16 times per KiB-step.  The asm keeps the compiler from folding the value back
+// into an SGPR or a literal.
+__device__ __forceinline__ uint32_t vgpr_const(uint32_t v) {
+    uint32_t r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v));
+    return r;
+}
+__device__ __forceinline__ ThrConst vgpr_consts(ThrConst tc) {
+    return ThrConst{vgpr_const(tc.ca), vgpr_const(tc.cb), vgpr_const(tc.h), vgpr_const(tc.w0), vgpr_const(tc.w1)};
 }
 
 // v_bitop3_b32: arbitrary 3-input boolean function; the truth table is written as an expression over
@@ -84,14 +99,14 @@ __device__ __forceinline__ uint32_t dword_flags(uint32_t a, uint32_t s, ThrConst
     const uint32_t sure = bitop3<(TA ^ TB) & ~(TA ^ TC)>(a, s, x);
     const uint32_t pos = bitop3<(TA & ~TB) | (~(TA ^ TB) & TC)>(a, s, x);
     const uint32_t mag = bitop3<(TA & TB) | (~TA & ~TC)>(pos, A, nB);
-    return HIGH ? bitop3<(TA & TB) & TC>(sure, mag, kH) : bitop3<(TA | TB) & TC>(sure, mag, kH);
+    return HIGH ? bitop3<(TA & TB) & TC>(sure, mag, tc.h) : bitop3<(TA | TB) & TC>(sure, mag, tc.h);
 }
 
 // per-byte (a - s) mod 256 from x: low 7 bits are x's, bit 7 is a7 ^ s7 ^ ~x7
 //                                                               (kernels.cu:314 `diff[npos] = df`)
-__device__ __forceinline__ uint32_t bytes_sub_from_x(uint32_t a, uint32_t s, uint32_t x) {
+__device__ __forceinline__ uint32_t bytes_sub_from_x(uint32_t a, uint32_t s, uint32_t x, uint32_t h = kH) {
     const uint32_t y = bitop3<(TA ^ TB ^ ~TC)>(a, s, x);
-    return bitop3<(TA & TB) | (~TA & TC)>(kH, y, x);
+    return bitop3<(TA & TB) | (~TA & TC)>(h, y, x);
 }
 
 // v_perm selector: byte j picks byte j of the first operand where flagged, of the second otherwise

@@ -321,6 +321,11 @@ int mi355_get_timing(mi355_core *core, double *ms_pack, double *ms_total, int *l
 /* The same sums per kernel: pack (k_diff_pack), scan (k_scan_groups), expand (k_expand); their sum is ms_total. */
 int mi355_get_kernel_timing(mi355_core *core, double *ms_pack, double *ms_scan, double *ms_expand, int *launches);
 int mi355_reset_timing(mi355_core *core);
+/* Diagnostics: the shader clock (MHz) the device holds under an integer-VALU load of about `milliseconds` ms
+ * (1..2000), measured inside a kernel as d(s_memtime) / d(s_memrealtime) x 100 MHz, median over all waves
+ * (csrc/diag.hip).  The diff path is bound by instruction issue, so its frames/s follow this clock; boards differ.
+ * Runs on the core's stream and returns after it has finished; not part of any data path. */
+int mi355_probe_clock(mi355_core *core, int milliseconds, double *shader_mhz);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/cudavideostream_amd/csrc
 OUT=$ROOT/build/ab
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off"
-ALL="core diff_pack filters stream_ops group"
+ALL="core diff_pack filters stream_ops group diag"
 [ -n "${EXPERIMENTS:-}" ] && { ALL="$ALL diff_fused diff_chain"; FLAGS="$FLAGS -DMI355_EXPERIMENTS=1"; }
 VAR_FILES=${AB_FILES:-diff_pack}
 mkdir -p $OUT/common

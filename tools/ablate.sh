@@ -11,7 +11,7 @@ for v in "$@"; do
   name=${v%%:*}; flags=${v#*:}
   d=gpurun_out/ablate/$name; mkdir -p $d
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off $flags -shared \
-      -o $d/libmi355diff.so cudavideostream_amd/csrc/core.hip cudavideostream_amd/csrc/diff_pack.hip cudavideostream_amd/csrc/diff_fused.hip cudavideostream_amd/csrc/diff_chain.hip cudavideostream_amd/csrc/filters.hip cudavideostream_amd/csrc/stream_ops.hip cudavideostream_amd/csrc/group.hip -ldl
+      -o $d/libmi355diff.so cudavideostream_amd/csrc/core.hip cudavideostream_amd/csrc/diff_pack.hip cudavideostream_amd/csrc/diff_fused.hip cudavideostream_amd/csrc/diff_chain.hip cudavideostream_amd/csrc/filters.hip cudavideostream_amd/csrc/stream_ops.hip cudavideostream_amd/csrc/group.hip cudavideostream_amd/csrc/diag.hip -ldl
   [ -n "${NO_STREAM:-}" ] || for rep in 1 2; do
     echo -n "$name stream: "; LD_LIBRARY_PATH=$d timeout -k 5 120 tools/diffbench --steps 20 ${DIFFBENCH_ARGS:-}
   done

@@ -1,0 +1,18 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-.}
+mkdir -p gpurun_out/r04m
+export TMPDIR=/tmp
+{
+REPS=1 bash tools/exp/run_matrix.sh "x8stamp seq|x8stamp|MI355_PIPELINE=0|"
+REPS=2 bash tools/exp/run_matrix.sh \
+ "x8 seq|x8|MI355_PIPELINE=0|" \
+ "x8 pipelined|x8||" \
+ "x8 two cores|x8||--cores 2"
+for v in x8; do
+LD_LIBRARY_PATH=build/ab/$v MI355_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r04m/trace_$v -- tools/diffbench --steps 10 > /dev/null 2>&1
+echo "== $v"; cat $(find gpurun_out/r04m/trace_$v -name "*kernel_stats.csv" | head -1) | cut -c1-150 | grep -v "webcam\|clock_probe\|rocclr"
+done
+timeout -k 10 300 python tools/bench_regimes.py
+timeout -k 10 900 python -m pytest tests/test_diff_pack_gpu.py tests/test_stream_ops_gpu.py tests/test_ref_f1f2_gpu.py tests/test_fuzz_gpu.py -x -q -m gpu 2>&1 | tail -5
+} > gpurun_out/r04m/log.txt 2>&1
+cat gpurun_out/r04m/log.txt
