@@ -33,6 +33,11 @@ class CUDAGroup {
 public:
     // ndev devices (0..ndev-1), frames of c columns x r rows, batches of up to max_batch frames
     CUDAGroup(int ndev, int r, int c, int max_batch, int threshold = 20) : g_(0) {
+        // the library loaded at run time must be the one this header describes (argument lists changed in round 3)
+        if (mi355_abi_version() != MI355_ABI_VERSION) {
+            fprintf(stderr, "libmi355diff: ABI version %d, this program was built for %d\n", mi355_abi_version(), MI355_ABI_VERSION);
+            exit(1);
+        }
         mi355_config cfg = mi355_config();
         cfg.width = c; cfg.height = r; cfg.threshold = threshold; cfg.max_batch = max_batch; cfg.device = -1;
         check(mi355_group_create(&cfg, ndev, 0, &g_), "mi355_group_create");

@@ -344,6 +344,16 @@ int setup_pipeline(mi355_core *c) {
     if (c->side || !c->pipeline_ok) return MI355_OK;
     const char *env = getenv("MI355_PIPELINE");
     if (env && env[0] == '0') { c->pipeline_ok = false; return MI355_OK; }
+    // Pipelined batches: the pack kernel on 4 workgroups per CU (16 waves: half of them walk a second tile) instead of
+    // one tile per wave (6 per CU).  It is bound by the memory system and does not need its occupancy (profiles/README.md,
+    // round 1), while the expansion of the batch before, which shares the chip with it, lives on the wave slots and
+    // registers that are left: 0.503-0.507 -> 0.487-0.497 ms per batch on the faster boxes, +-1 % on the slower ones
+    // (profiles/r04p, r04q, r04v).  MI355_K1_BLOCKS=n overrides (0 = one tile per wave).
+    {
+        hipDeviceProp_t prop{};
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
+            c->k1_blocks = 4u * (uint32_t)prop.multiProcessorCount;
+    }
     if (const char *b = getenv("MI355_K1_BLOCKS")) c->k1_blocks = (uint32_t)atoi(b);   // tuning knob (tools/, profiles/)
     if (const char *b = getenv("MI355_SCAN_MAIN")) c->scan_on_main = b[0] == '1';
     int side_prio = 0;
@@ -365,8 +375,12 @@ int setup_pipeline(mi355_core *c) {
         ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
     }
     for (int i = 0; i < 2 && ok; i++) {
-        ok = hipEventCreateWithFlags(&c->set[i].packed, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&c->set[i].expanded, hipEventDisableTiming) == hipSuccess;
+        // device-scope release: these events only order kernels of this device against each other.  An event's default
+        // is a SYSTEM-scope fence when it is recorded (caches written back and invalidated for the host's benefit),
+        // which every batch paid twice on the core's stream between two pack kernels
+        const unsigned flags = hipEventDisableTiming | (getenv("MI355_EVENT_SYSFENCE") ? 0u : hipEventReleaseToDevice);
+        ok = hipEventCreateWithFlags(&c->set[i].packed, flags) == hipSuccess &&
+             hipEventCreateWithFlags(&c->set[i].expanded, flags) == hipSuccess;
     }
     if (!ok) {   // not an error: the batches then run one after the other, as with a caller's stream
         (void)hipGetLastError();
@@ -518,6 +532,8 @@ extern "C" {
 
 const char *mi355_last_error(void) { return g_err.c_str(); }
 
+int mi355_abi_version(void) { return MI355_ABI_VERSION; }
+
 int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (!cfg || !out) return fail(MI355_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -534,8 +550,14 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (n64 >= (1ull << 31)) return fail(MI355_ERR_INVALID, "frame larger than 2 GiB");
     // byte indices are int32 and batch offsets uint32 (the reference's h_xs / h_pos types)
     // (whole tiles: the record log, max_batch * ceil(N / 1024) KiB, is addressed with 32-bit byte offsets)
-    if (((n64 + kTileBytes - 1) / kTileBytes * kTileBytes) * (uint64_t)cfg->max_batch >= (1ull << 32))
-        return fail(MI355_ERR_INVALID, "max_batch * frame bytes must stay below 2^32");
+    // ... and so is the code log, code_chunks(max_batch) * ceil(N / 1024) KiB, which is the larger one for max_batch = 1
+    // (two chunks per tile: a frame's codes never straddle a chunk)
+    {
+        const uint64_t tiles = (n64 + kTileBytes - 1) / kTileBytes, mb = (uint64_t)cfg->max_batch;
+        const uint64_t chunks = mb > code_chunks((size_t)mb) ? mb : (uint64_t)code_chunks((size_t)mb);
+        if (tiles * kTileBytes * chunks >= (1ull << 32))
+            return fail(MI355_ERR_INVALID, "max_batch * frame bytes must stay below 2^32");
+    }
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -555,7 +577,7 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     int rc = use_device(c);
     if (!rc) { e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipStreamCreate", e); }
     c->stream = c->own_stream;
-    for (int i = 0; i < mi355_core::kEvRing * mi355_core::kEvPer && !rc; i++) { e = hipEventCreate(&c->ev[i / mi355_core::kEvPer][i % mi355_core::kEvPer]); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipEventCreate", e); }
+    for (int i = 0; i < mi355_core::kEvRing * mi355_core::kEvPer && !rc; i++) { e = hipEventCreateWithFlags(&c->ev[i / mi355_core::kEvPer][i % mi355_core::kEvPer], getenv("MI355_EVENT_SYSFENCE") ? hipEventDefault : hipEventDisableSystemFence); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipEventCreate", e); }   // timing events: no system-scope fence (hip_runtime_api.h: "can improve the accuracy of timing measurements by avoiding the cost of cache writeback and invalidation")
     if (!rc && (e = init_gray_table()) != hipSuccess) rc = fail(MI355_ERR_HIP, "init_gray_table", e);
     if (!rc) rc = dev_alloc(c, &c->state, N + 16);
     if (!rc) rc = dev_alloc(c, &c->in, N + 16);

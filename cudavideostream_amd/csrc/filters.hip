@@ -734,7 +734,10 @@ __global__ __launch_bounds__(256) void k_red_stream_clear(uint8_t *out, size_t s
     // slices are whole pixels: x in [a, a + len) <=> the painted byte x + (2 - x % 3) in it  (kernels.cu:273-281)
     for (uint32_t i = lo + lane; i < hi; i += 64u) {
         const uint32_t x = (uint32_t)xs[first + i] - a;
-        bytes[x + (2u - x % 3u)] = 255;                    // a is a multiple of 3: (x - a) % 3 == x % 3
+        // a is a multiple of 3: (x - a) % 3 == x % 3.  Entries outside the slice (a caller-built stream that is not
+        // ascending, or the uninitialised tail of a batch that overflowed its capacity) are dropped: without the
+        // guard they would paint into a neighbouring wave's slice or outside the LDS array
+        if (x < len) bytes[x + (2u - x % 3u)] = 255;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();

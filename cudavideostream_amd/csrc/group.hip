@@ -270,12 +270,13 @@ int mi355_group_gather(mi355_group *g, int root, int nframes, const void *const 
                        const void *const *d_diff, size_t member_capacity, void *d_root_offsets, void *d_root_xs,
                        void *d_root_diff, size_t root_capacity, uint64_t *h_counts) {
     if (int rc = check_group(g)) return rc;
-    if (root < 0 || root >= g->nranks) return set_error(MI355_ERR_INVALID, "root outside [0, ranks)");
-    if (nframes < 0) return set_error(MI355_ERR_INVALID, "nframes < 0");
-    if (!d_offsets || !d_xs || !d_diff) return set_error(MI355_ERR_INVALID, "null argument");
-    Member *rootm = member_of_rank(g, root);
     // Arguments only this process can judge are folded into what the ranks exchange (word 3), so that a bad call
-    // on one rank fails the gather on EVERY rank instead of leaving the others with sends nobody receives.
+    // on one rank fails the gather on EVERY rank instead of leaving the others in an all-gather or with sends nobody
+    // receives: a root out of range, nframes < 0 or above 2^23, null arrays (bit 1), missing root buffers (bit 0).
+    // The ranks' nframes travel in the same word (bits 8..31) and must agree.
+    bool bad_local = root < 0 || root >= g->nranks || nframes < 0 || nframes >= (1 << 23) || !d_offsets || !d_xs || !d_diff;
+    for (size_t i = 0; i < g->local.size() && !bad_local; i++) bad_local = !d_offsets[i];
+    Member *rootm = bad_local ? nullptr : member_of_rank(g, root);
     const bool bad_root_args = rootm && (!d_root_offsets || (root_capacity && (!d_root_xs || !d_root_diff)));
     const int R = g->nranks;
     const uint32_t kMax = 0xFFFFFFFFu;
@@ -290,10 +291,11 @@ int mi355_group_gather(mi355_group *g, int root, int nframes, const void *const 
         m.h_send[0] = 0;
         m.h_send[1] = member_capacity > kMax ? kMax : (uint32_t)member_capacity;
         m.h_send[2] = m.rank == root ? (root_capacity > kMax ? kMax : (uint32_t)root_capacity) : 0u;
-        m.h_send[3] = m.rank == root && bad_root_args ? 1u : 0u;
+        m.h_send[3] = (m.rank == root && bad_root_args ? 1u : 0u) | (bad_local ? 2u : (uint32_t)nframes << 8);
         hipError_t e = hipSetDevice(core_device(m.core));
         if (e == hipSuccess) e = hipMemcpyAsync(m.d_send, m.h_send, sizeof m.h_send, hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(m.d_send, (const uint32_t *)d_offsets[i] + nframes, sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess && !bad_local)
+            e = hipMemcpyAsync(m.d_send, (const uint32_t *)d_offsets[i] + nframes, sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) { rc = set_error(MI355_ERR_HIP, hipGetErrorString(e)); break; }
         const ncclResult_t r = g_rccl.AllGather(m.d_send, m.d_counts, kWords, ncclUint32, m.comm, s);
         if (r != ncclSuccess) rc = rccl_fail("ncclAllGather", r);
@@ -308,18 +310,24 @@ int mi355_group_gather(mi355_group *g, int root, int nframes, const void *const 
         HIP_TRY_G(hipStreamSynchronize(core_stream(m.core)));
     }
     std::vector<size_t> base(R + 1, 0);
-    bool member_overflow = false, bad_args = false;
+    bool member_overflow = false, bad_root = false, bad_call = false, frames_differ = false;
     for (int r = 0; r < R; r++) {
         const uint32_t *w = &g->h_all[(size_t)r * kWords];
         g->h_counts[r] = w[0];
         base[r + 1] = base[r] + w[0];
         if (h_counts) h_counts[r] = w[0];
         member_overflow |= w[0] > w[1];
-        bad_args |= w[3] != 0;
+        bad_root |= (w[3] & 1u) != 0;
+        bad_call |= (w[3] & 2u) != 0;
+        frames_differ |= (w[3] >> 8) != (g->h_all[3] >> 8);
     }
-    const size_t root_cap = g->h_all[(size_t)root * kWords + 2];
     // the same verdict on every rank: nothing has been sent yet, nobody waits for anybody
-    if (bad_args) return set_error(MI355_ERR_INVALID, "the root's buffers are missing (the root is a member of some process)");
+    if (bad_call)
+        return set_error(MI355_ERR_INVALID, bad_local ? "root outside [0, ranks), nframes outside [0, 2^23) or null argument"
+                                                      : "another rank called the gather with invalid arguments");
+    if (frames_differ) return set_error(MI355_ERR_INVALID, "the ranks disagree about nframes");
+    if (bad_root) return set_error(MI355_ERR_INVALID, "the root's buffers are missing (the root is a member of some process)");
+    const size_t root_cap = g->h_all[(size_t)root * kWords + 2];
     if (member_overflow)
         return set_error(MI355_ERR_INVALID, "a member's batch holds more entries than its buffers (member_capacity): "
                                             "entries beyond the capacity were dropped, there is nothing to gather from");

@@ -44,6 +44,7 @@ SYMBOLS = {
     "mi355_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
     "mi355_destroy": (None, [C.c_void_p]),
     "mi355_last_error": (C.c_char_p, []),
+    "mi355_abi_version": (C.c_int, []),
     "mi355_frame_bytes": (C.c_size_t, [C.c_void_p]),
     "mi355_workspace_bytes": (C.c_size_t, [C.c_void_p]),
     "mi355_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -119,6 +120,7 @@ SYMBOLS = {
     "mi355_group_synchronize": (C.c_int, [C.c_void_p]),
 }
 GROUP_ID_BYTES = 128   # MI355_GROUP_ID_BYTES
+ABI_VERSION = 4        # MI355_ABI_VERSION of the include/mi355diff.h these argument lists were written against
 
 _lib = None
 
@@ -150,6 +152,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.mi355_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} has ABI version {lib.mi355_abi_version()}, this binding was written for {ABI_VERSION}: "
+                           "rebuild the library (make -C cudavideostream_amd/csrc)")
     _lib = lib
     return lib
 

@@ -68,19 +68,37 @@ typedef struct mi355_config {
  * ones (csrc/diff_chain.hip says why).  Also MI355_CHAIN=1 in the environment. */
 #define MI355_FLAG_CHAIN 2
 
+/* ABI version of this header: bumped whenever an existing entry point changes its argument list (round 3 did that to
+ * mi355_group_gather without a marker: a caller built against the older header still linked and passed shifted
+ * arguments).  A binding checks mi355_abi_version() == MI355_ABI_VERSION when it loads the library
+ * (cudavideostream_amd/lib.py, compat/include/group.hpp do).
+ *   3  round 3: mi355_group_gather gained member_capacity (6th argument)
+ *   4  round 4: + mi355_abi_version, mi355_probe_clock (additions only) */
+#define MI355_ABI_VERSION 4
+int mi355_abi_version(void);
+
 /* ---- life cycle: CUDACore::CUDACore (kernels.cu:377-428) without the uploads ------------------ */
 int mi355_create(const mi355_config *cfg, mi355_core **out);
 void mi355_destroy(mi355_core *core);
 const char *mi355_last_error(void);
 /* Size in bytes of one frame (3*width*height). */
 size_t mi355_frame_bytes(const mi355_core *core);
-/* Bytes of HBM workspace held by the core (state, logs, counters). */
+/* Bytes of HBM workspace held by the core (state, logs, counters).  The logs are sized for the worst case (every byte
+ * of every frame of a batch changed): about (1 + 1/3) * max_batch * N bytes, 2.07 GB for 1080p and max_batch 256.  The
+ * first asynchronous batch call on the core's own stream allocates a second set (hipMalloc + hipMemset inside that
+ * call: it is not asynchronous) for the pipelined mode below; scratch buffers of the fused gray+binarize chain and of
+ * the cleared red map are likewise allocated by the first call that needs them. */
 size_t mi355_workspace_bytes(const mi355_core *core);
 
-/* A core starts on a stream of its own.  mi355_set_stream makes it enqueue on an existing hipStream_t
- * instead (e.g. PyTorch's current stream; NULL is the default stream), so that the caller's own work
- * on that stream is ordered with the core's; mi355_use_own_stream goes back.  Both wait for the work already
- * queued on the stream being left (all batches of a core share one workspace). */
+/* Streams.  A core starts on a stream of its own, created hipStreamNonBlocking: it is NOT ordered against the
+ * legacy default stream nor against any other stream of the caller.  Buffers the caller fills asynchronously on
+ * another stream (hipMemcpyAsync, a framework's kernels) must be complete -- hipStreamSynchronize / an event the
+ * caller waits for -- before an asynchronous entry point of the core reads them, and the caller must
+ * mi355_synchronize (or use the blocking entry points) before it reads the outputs on another stream.
+ * mi355_set_stream makes the core enqueue on an existing hipStream_t instead (e.g. PyTorch's current stream; NULL is
+ * the default stream), so that the caller's own work on that stream is ordered with the core's; mi355_use_own_stream
+ * goes back.  Both wait for the work already queued on the stream being left (all batches of a core share one
+ * workspace). */
 int mi355_set_stream(mi355_core *core, void *hip_stream);
 int mi355_use_own_stream(mi355_core *core);
 int mi355_synchronize(mi355_core *core);
@@ -206,8 +224,9 @@ int mi355_median5x5(mi355_core *core, const void *d_in, void *d_out);
 
 /* Batched form of the per-frame filters: nframes frames at d_in + t*stride_bytes (and d_in2 + t*stride_bytes
  * for the two-input filters) -> d_out + t*stride_bytes, one launch per kernel for the whole batch.
- * The *_BINARIZE ops compute one histogram and one two-max threshold per frame; the fused forms read
- * the colour frame twice and never materialise the gray frame (BASELINE config 3). */
+ * The *_BINARIZE ops compute one histogram and one two-max threshold per frame; the fused forms read the colour
+ * frame ONCE: pass 1 converts it and keeps one gray byte per pixel in a scratch of the core (max_batch * N/3 bytes,
+ * allocated at the first such call) beside the histogram, pass 2 binarizes from that scratch (BASELINE config 3). */
 #define MI355_OP_GRAY_AVG 1                /* kernels.cu:31-43                         */
 #define MI355_OP_GRAY_WEIGHTED 2           /* kernels.cu:67-95                         */
 #define MI355_OP_BINARIZE 3                /* gray3 in: kernels.cu:138-241             */

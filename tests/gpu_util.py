@@ -12,14 +12,39 @@ _DEVICE_CALLS = {"diff_stream_batch", "diff_pairs_batch", "diff_stream_wire_batc
 
 
 class CUDACore(_CUDACore):
-    """The product class with one test-side addition: a core runs on a non-blocking stream of its own, so
-    buffers the tests fill with torch (uploads, torch.full on torch's stream) must be complete before a
-    device-resident entry point is enqueued.  Looking up such a method first drains torch's streams."""
+    """The product class with one test-side addition: a core runs on a non-blocking stream of its own, which is NOT
+    ordered against torch's streams (include/mi355diff.h, "Streams"), so buffers the tests fill with torch (uploads,
+    torch.full on torch's stream) must be complete before a device-resident entry point is enqueued.  Every such entry
+    point is wrapped: torch's streams are drained when the method is CALLED -- not when it is looked up (round 3's
+    harness did that, and a method bound before the last torch.full raced with the fill: 1 failure in 12 runs)."""
 
-    def __getattribute__(self, name):
-        if name in _DEVICE_CALLS:
-            torch.cuda.synchronize()
-        return object.__getattribute__(self, name)
+
+def _synced(name):
+    inner = getattr(_CUDACore, name)
+
+    def call(self, *args, **kwargs):
+        torch.cuda.synchronize()
+        # the call is asynchronous on the core's stream: tensors handed in as temporaries (core.conv3x3(to_dev(a), out))
+        # must outlive it, or torch's allocator gives their memory to the next to_dev() while the kernel still reads it
+        keep = self.__dict__.setdefault("_keepalive", [])
+        keep.extend(a for a in list(args) + list(kwargs.values()) if torch.is_tensor(a))
+        return inner(self, *args, **kwargs)
+
+    call.__name__ = name
+    call.__doc__ = inner.__doc__
+    return call
+
+
+for _name in _DEVICE_CALLS:
+    setattr(CUDACore, _name, _synced(_name))
+
+
+def _synchronize(self):
+    _CUDACore.synchronize(self)
+    self.__dict__.pop("_keepalive", None)
+
+
+CUDACore.synchronize = _synchronize
 
 
 def to_dev(a):

@@ -58,6 +58,11 @@ def test_argument_validation_without_gpu(built):
     assert b"threshold" in built.mi355_last_error()
     bad = lib.Config(1920, 1080, 20, 1000, -1, 0, 0, 0)  # 1000 * 6.2 MB >= 2^32
     assert built.mi355_create(C.byref(bad), C.byref(h)) == lib.ERR_INVALID
+    # max_batch = 1: the code log (two KiB chunks per tile) is the larger log; a frame within 1 KiB of 2^31 bytes would
+    # wrap its 32-bit byte offsets (the record log alone, one KiB per tile, would pass)
+    bad = lib.Config(2, 357913771, 20, 1, -1, 0, 0, 0)   # 2 147 482 626 bytes < 2^31: 2^21 tiles, two KiB chunks each = 2^32
+    assert built.mi355_create(C.byref(bad), C.byref(h)) == lib.ERR_INVALID
+    assert b"2^32" in built.mi355_last_error()
     assert built.mi355_synchronize(None) == lib.ERR_INVALID
     assert built.mi355_frame_bytes(None) == 0
 

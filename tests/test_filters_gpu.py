@@ -318,6 +318,37 @@ def test_red_stream_clear_many_slices(po, w, h):
             assert np.array_equal(got[t, n:], canvas[t, n:])
 
 
+def test_red_stream_clear_drops_entries_outside_their_slice():
+    """A caller-built stream that is NOT ascending (the cleared form's search then hands a wave entries of other
+    slices): such entries are dropped; no pixel outside the owning slice changes and the padding stays untouched."""
+    w, h = 640, 360
+    n = 3 * w * h
+    rng = np.random.default_rng(7)
+    good = np.sort(rng.choice(n, 5000, replace=False)).astype(np.int32)
+    xs = good.copy()
+    # entries far away from where the ascending order would put them (a later slice's index early in the stream
+    # and the other way round), plus indices beyond the frame
+    xs[10], xs[4000] = good[4900], good[5]
+    xs[2500] = np.int32(n + 12345)
+    stride = (n + 15) // 16 * 16 + 16
+    canvas = rng.integers(1, 200, (1, stride), dtype=np.uint8)
+    with CUDACore(w, h, max_batch=1) as core:
+        d_canvas = to_dev(canvas)
+        core.red_stream_batch(to_dev(np.array([0, xs.size], np.uint32).view(np.int32)), to_dev(xs), 1, d_canvas,
+                              clear=True, stride=stride)
+        core.synchronize()
+        got = d_canvas.cpu().numpy()[0]
+    assert np.array_equal(got[n:], canvas[0, n:])
+    painted = np.flatnonzero(got[:n])
+    assert np.all(got[painted] == 255) and np.all(painted % 3 == 2)
+    # every painted pixel is owned by an in-range entry of the stream (no stray writes into neighbouring slices)
+    inrange = xs[(xs >= 0) & (xs < n)]
+    owners = set((inrange - inrange % 3 + 2).tolist())
+    assert set(painted.tolist()) <= owners
+    # (which of the other entries still land in the slice the search assigns them to is not defined for such a stream)
+    assert painted.size > 0
+
+
 # ---- exec_core: the per-frame host path (kernels.cu:430-525) ---------------------------------------
 
 def oracle_exec(po, frame, state, vis, k, noise_filter, w, h):

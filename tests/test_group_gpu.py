@@ -230,6 +230,20 @@ def rank_main(r):
                     res.append("no error")
                 except lib.Mi355Error as e:
                     res.append("member" if "member_capacity" in str(e) else "other: " + str(e))
+                # (2b) rank 0 calls with a negative nframes, (2c) rank 2 with another nframes than its peers: programmer
+                # errors of ONE rank, reported on every rank -- nobody is left inside the all-gather
+                barrier.wait()
+                try:
+                    grp.gather(root, -1 if r == 0 else T, [d_off], [d_xs], [d_df], T * n, r_off, r_xs, r_df, R * T * n if r == root else 0)
+                    res.append("no error")
+                except lib.Mi355Error as e:
+                    res.append("call" if ("invalid arguments" in str(e) or "nframes outside" in str(e)) and e.code == lib.ERR_INVALID else "other: " + str(e))
+                barrier.wait()
+                try:
+                    grp.gather(root, T - 1 if r == 2 else T, [d_off], [d_xs], [d_df], T * n, r_off, r_xs, r_df, R * T * n if r == root else 0)
+                    res.append("no error")
+                except lib.Mi355Error as e:
+                    res.append("frames" if "disagree about nframes" in str(e) else "other: " + str(e))
                 # (3) and the group is still usable: the real gather
                 barrier.wait()
                 counts = grp.gather(root, T, [d_off], [d_xs], [d_df], T * n, r_off, r_xs, r_df, R * T * n if r == root else 0)
@@ -254,7 +268,7 @@ for t in threads: t.join(timeout=200)
 assert not any(t.is_alive() for t in threads), "a rank hangs"
 tots = [int(want[r][0][-1]) for r in range(R)]
 for r in range(R):
-    assert outcome[r] == ["capacity", "member", tots], (r, outcome[r])
+    assert outcome[r] == ["capacity", "member", "call", "frames", tots], (r, outcome[r])
 at = 0
 for r in range(R):
     eo, exs, edf, _ = want[r]
@@ -266,9 +280,9 @@ print("THREADS-OK")
 
 
 def test_one_member_per_process_protocol_with_threads(mock_rccl):
-    """Three ranks, one per thread (the one-member-per-process form): a root capacity that is too small and a member
-    whose batch overflowed are reported on EVERY rank, before anything is sent; the gather that follows delivers the
-    oracle's streams at root 1."""
+    """Three ranks, one per thread (the one-member-per-process form): a root capacity that is too small, a member
+    whose batch overflowed, one rank's invalid nframes and ranks that disagree about nframes are reported on EVERY rank,
+    before anything is sent; the gather that follows delivers the oracle's streams at root 1."""
     code = CHILD_THREADS % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=400,
                          env=dict(mock_rccl, MOCK_RCCL_TIMEOUT_S="30"), cwd=ROOT)

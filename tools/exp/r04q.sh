@@ -16,3 +16,4 @@ echo "== timeline $cfg"; python3 tools/exp/timeline.py $(find gpurun_out/r04q/tl
 done
 } > gpurun_out/r04q/log.txt 2>&1
 cat gpurun_out/r04q/log.txt
+timeout -k 10 900 python -m pytest tests/test_group_gpu.py tests/test_filters_gpu.py tests/test_diff_pack_gpu.py -x -q -m gpu 2>&1 | tail -5 | tee -a gpurun_out/r04q/log.txt
