@@ -75,7 +75,7 @@ def path_roofline(alg_bytes, ms, launches, pair, pmc=None, wall_ms=None):
     per = [m / max(launches, 1) for m in ms]
     total_ms = wall_ms if wall_ms is not None else sum(per)
     achieved = alg_bytes / (total_ms * 1e-3) / 1e9
-    names = ("mi355::k_diff_pack<%s,true>" % ("true" if pair else "false"), "mi355::k_scan_groups",
+    names = ("mi355::k_diff_pack<%s,true,false>" % ("true" if pair else "false"), "mi355::k_scan_groups",
              "mi355::k_expand<false>")
     kernels = []
     for short, name, m in zip(KERNELS, names, per):
@@ -100,6 +100,39 @@ def path_roofline(alg_bytes, ms, launches, pair, pmc=None, wall_ms=None):
     if pmc:
         out["traffic_source"] = f"profiles/pmc_summary.json ({pmc.get('tag')}, separate --pmc FETCH_SIZE / WRITE_SIZE passes, same library build)"
         out["actual_gbps"] = round(pmc["hbm_bytes_per_launch"] / (total_ms * 1e-3) / 1e9, 1)
+    return out
+
+
+def smi_snapshot():
+    """sclk / mclk / power of the board as rocm-smi reports them (outside every timed region); None where the tool is
+    missing or refuses.  Explains nothing by itself under load (the guide: in-kernel clocks read up to 10 % below
+    pp_dpm_sclk), so the in-kernel probes of `board` go with it."""
+    import subprocess
+    try:
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--json"],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=20)
+        d = json.loads(r.stdout.decode(errors="replace") or "{}")
+        card = d.get("card0") or (next(iter(d.values())) if d else {})
+        keep = {}
+        for k, v in card.items():
+            lk = k.lower()
+            if any(t in lk for t in ("sclk", "mclk", "fclk", "power", "performance level")) and "socclk" not in lk:
+                keep[k] = v
+        return keep or None
+    except Exception:   # noqa: BLE001
+        return None
+
+
+def board_fingerprint(core, when):
+    """What this board holds under load, measured inside kernels right after the timed region (the chip is warm):
+    the shader clock under an integer-VALU load and the GB/s of a plain streaming read.  The path's frames/s follow the
+    second (the pack kernel is bound by the memory system), and boards of the pool differ by ~7 % in it."""
+    out = {"when": when}
+    try:
+        out["shader_mhz_under_valu_load"] = round(core.probe_clock(100), 0)
+        out["hbm_stream_read_gbps"] = round(core.probe_hbm_read(2048), 0)
+    except Exception as e:   # noqa: BLE001
+        out["skipped"] = repr(e)[:120]
     return out
 
 
@@ -199,6 +232,83 @@ def cpu_baseline(args, base, frames, dev):
     return base_obj, bool(ok)
 
 
+def parity_of_secondary_lines(args, dev, frames):
+    """One sample of every workload the line quotes a number for, product against oracle (bit-exact), outside the
+    timed regions: pair mode, the three regimes, config 3, config 4.  (The headline's parity is cpu_baseline's.)"""
+    from oracle import pyoracle as po
+    from cudavideostream_amd import lib as L
+    W, H = args.width, args.height
+    n = 3 * W * H
+    res = {}
+
+    def pairs_ok(cur, prev):
+        T = cur.shape[0]
+        with CUDACore(W, H, max_batch=T) as c:
+            c.use_torch_stream()
+            cap = T * n
+            d_off = torch.zeros(T + 1, dtype=torch.int32, device=dev)
+            d_xs = torch.empty(cap, dtype=torch.int32, device=dev)
+            d_df = torch.empty(cap, dtype=torch.uint8, device=dev)
+            c.diff_pairs_batch(cur, prev, T, d_off, d_xs, d_df, cap)
+            torch.cuda.synchronize()
+            off = d_off.cpu().numpy().view(np.uint32)
+            hx, hd = d_xs[:int(off[-1])].cpu().numpy(), d_df[:int(off[-1])].cpu().numpy()
+        hc, hp = cur.cpu().numpy(), prev.cpu().numpy()
+        ok = True
+        for t in range(T):
+            cnt, xs, df, _ = po.diff_pack(hc[t], hp[t])
+            ok = ok and off[t + 1] - off[t] == cnt and np.array_equal(hx[off[t]:off[t + 1]], xs) and np.array_equal(hd[off[t]:off[t + 1]], df)
+        return bool(ok)
+
+    B = frames.shape[0] // 2
+    res["pair"] = pairs_ok(frames[:2], frames[B:B + 2])
+    rnd = torch.stack([synth.refrand_frame(n, 100 + t, device=dev) for t in (0, 1, 32, 33)])
+    res["S0"] = pairs_ok(rnd[2:], rnd[:2])
+    res["P_eq_N"] = pairs_ok(rnd[:2] ^ 0x80, rnd[:2])
+    res["P_eq_0"] = pairs_ok(rnd[:2], rnd[:2].clone())
+
+    # config 3 / config 4 on two frames of the filter workload's stream
+    _, fr = synth.webcam_stream(3, W, H, seed=33, device=dev)
+    h = fr.cpu().numpy()
+    g = np.exp(-(np.arange(-1, 2)[:, None] ** 2 + np.arange(-1, 2)[None, :] ** 2) / (2.0 * 1.5 * 1.5))
+    k = (g / g.sum()).astype(np.float32).reshape(-1)
+    T = 2
+    with CUDACore(W, H, k=k, max_batch=T) as c:
+        c.use_torch_stream()
+        cap = T * n
+        d_off = torch.zeros(T + 1, dtype=torch.int32, device=dev)
+        d_xs = torch.empty(cap, dtype=torch.int32, device=dev)
+        d_df = torch.empty(cap, dtype=torch.uint8, device=dev)
+        vis = torch.empty((T, n), dtype=torch.uint8, device=dev)
+        filt = torch.empty((T, n), dtype=torch.uint8, device=dev)
+        # config 3: weighted gray -> histogram -> two-max -> binarize, then the diff of the colour frames
+        c.set_state(h[0])
+        c.filter_batch(L.OP_GRAY_WEIGHTED_BINARIZE, fr[1:], vis, T)
+        c.diff_stream_batch(fr[1:], T, d_off, d_xs, d_df, cap)
+        torch.cuda.synchronize()
+        eo, exs, edf, _ = po.diff_stream(h[1:], h[0])
+        ok3 = np.array_equal(d_off.cpu().numpy().view(np.uint32), eo) and np.array_equal(d_xs[:int(eo[-1])].cpu().numpy(), exs) \
+            and np.array_equal(d_df[:int(eo[-1])].cpu().numpy(), edf)
+        for t in range(T):
+            g3 = po.gray_weighted(h[1 + t])
+            ok3 = ok3 and np.array_equal(vis[t].cpu().numpy(), po.binarize(g3, po.two_max_threshold(po.histogram(g3))))
+        res["config3"] = bool(ok3)
+        # config 4: noise filter, diff of the filtered frames, cleared red map from the packed indices
+        c.set_state(h[0])
+        c.filter_batch(L.OP_CONV3X3, fr[1:], filt, T)
+        c.diff_stream_batch(filt, T, d_off, d_xs, d_df, cap)
+        c.red_stream_batch(d_off, d_xs, T, vis)
+        torch.cuda.synchronize()
+        hf = np.stack([po.conv3x3(h[1 + t], W, H, k) for t in range(T)])
+        eo, exs, edf, _ = po.diff_stream(hf, h[0])
+        ok4 = np.array_equal(filt.cpu().numpy(), hf) and np.array_equal(d_off.cpu().numpy().view(np.uint32), eo) \
+            and np.array_equal(d_xs[:int(eo[-1])].cpu().numpy(), exs) and np.array_equal(d_df[:int(eo[-1])].cpu().numpy(), edf)
+        for t in range(T):
+            ok4 = ok4 and np.array_equal(vis[t].cpu().numpy(), po.red_overlap(np.zeros(n, np.uint8), exs[eo[t]:eo[t + 1]]))
+        res["config4"] = bool(ok4)
+    return res
+
+
 def reference_filter_chain(args, h_base, h_frames, nframes=8):
     """Part of the cpu_baseline leg: the reference's OWN CPU branch for the gray-avg -> histogram -> two-max ->
     binarize chain (server/src/server.cpp:96-135, compiled unmodified into oracle/_ref/server_cpu where the
@@ -277,6 +387,7 @@ def main():
     W, H, B, K = args.width, args.height, args.batch, args.steps
     n = 3 * W * H
     rr = args.shard == "roundrobin"
+    smi_before = smi_snapshot() if rank == 0 else None
     if rr:   # local frame k is global frame rank + k*world; its predecessor travels with it
         mine = gx.roundrobin_frames(rank, world, B * world)
         base = synth.webcam_frame(-1, W, H, seed=21, device=dev)
@@ -361,6 +472,7 @@ def main():
             if args.gather == "every" or (args.gather in ("last", "index") and last):
                 exchange_payload()
             elif args.gather == "index":
+                core.synchronize()   # d_off is written on the core's side stream; torch.distributed runs on torch's
                 gx.gather_index(d_off, dst=0)
 
     for i in range(args.warmup):
@@ -460,14 +572,28 @@ def main():
             out.update(filter_configs(args, dev))
         if world == 1 and not args.no_host_path:
             out["host_path"] = host_path(args, base, frames)
+        out["board"] = board_fingerprint(core, "right after the timed region")
+        out["board"]["rocm_smi_before"] = smi_before
+        out["board"]["rocm_smi_after"] = smi_snapshot()
+        parity_failed = False
         if world == 1 and not args.no_cpu and not rr:
-            out["cpu_baseline"], out["parity"] = cpu_baseline(args, base, frames, dev)
+            out["cpu_baseline"], headline_ok = cpu_baseline(args, base, frames, dev)
+            # parity next to every number of the line (product vs oracle, bit-exact, outside the timed regions)
+            par = {"headline": headline_ok}
+            if not args.no_pair or not args.no_filters:
+                par.update(parity_of_secondary_lines(args, dev, frames))
+            out["parity"] = par
+            parity_failed = not all(par.values())
         else:
             out["cpu_baseline"] = None
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
+        if parity_failed:
+            print(f"bench.py: PARITY FAILED: {out['parity']}", file=sys.stderr)
+            core.close()
+            raise SystemExit(4)
     if group is not None:
         group.close()
     core.close()
@@ -663,8 +789,8 @@ def filter_configs(args, dev, B=96, reps=10):
     k = (g / g.sum()).astype(np.float32).reshape(-1)
     res = {}
     with CUDACore(W, H, k=k, max_batch=B) as core:
-        core.use_torch_stream()
         core.set_state(frames[0].cpu().numpy())
+        torch.cuda.synchronize()
 
         def config3():
             core.filter_batch(L.OP_GRAY_WEIGHTED_BINARIZE, cur, vis, B)
@@ -675,26 +801,37 @@ def filter_configs(args, dev, B=96, reps=10):
             core.diff_stream_batch(filt, B, d_off, d_xs, d_df, cap)
             core.red_stream_batch(d_off, d_xs, B, vis)
 
-        # config3's algorithmic bytes: 3N + 5P -- BASELINE names the chain "fused, sharing the diff's loads": colour
-        # frame read once (N), binarized frame written (N), state (N), 5P out; config4: 5N + 5P
-        for name, fn, fixed in (("config3", config3, 3.0 * n), ("config4", config4, 5.0 * n)):
+        def wall_us(fn):
             for _ in range(3):
                 fn()
+            core.synchronize()
             torch.cuda.synchronize()
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
+            t0 = time.perf_counter()
             for _ in range(reps):
                 fn()
-            ev1.record()
-            torch.cuda.synchronize()
-            us = ev0.elapsed_time(ev1) * 1e3 / (reps * B)
+            core.synchronize()
+            return (time.perf_counter() - t0) * 1e6 / (reps * B)
+
+        # config3's algorithmic bytes: 3N + 5P -- BASELINE names the chain "fused, sharing the diff's loads": colour
+        # frame read once (N), binarized frame written (N), state (N), 5P out; config4: 5N + 5P.
+        # Timed twice: on the core's OWN stream, the way the library is meant to run (the frame filter of batch k + 1
+        # beside the expansion of batch k, include/mi355diff.h), wall clock between device synchronisations; and one
+        # batch after the other on a caller's stream (`sequential_us_per_frame`).
+        for name, fn, fixed in (("config3", config3, 3.0 * n), ("config4", config4, 5.0 * n)):
+            core.use_own_stream()
+            us = wall_us(fn)
+            core.use_torch_stream()
+            us_seq = wall_us(fn)
             p = (int(d_off[B].item()) & 0xFFFFFFFF) / B
             alg = fixed + 5.0 * p
             gbps = alg / (us * 1e-6) / 1e9
             res[name] = {"workload": BASELINE_CONFIGS.get(name, name), "us_per_frame": round(us, 3),
+                         "sequential_us_per_frame": round(us_seq, 3),
                          "frames_per_s": round(1e6 / us, 1), "frames_per_launch": B,
                          "changed_bytes_per_frame": round(p, 1), "algorithmic_bytes_per_frame": int(alg),
-                         "achieved_gbps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4)}
+                         "achieved_gbps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                         "basis": "wall clock per frame on the core's own stream (filters of a batch beside the expansion of "
+                                  "the batch before); sequential_us_per_frame: the same calls on a caller's stream"}
     return res
 
 

@@ -286,6 +286,12 @@ class CUDACore:
         _l.check(self._lib.mi355_probe_clock(self._h, int(milliseconds), C.byref(mhz)))
         return mhz.value
 
+    def probe_hbm_read(self, megabytes=2048):
+        """GB/s of a plain streaming read on this board (csrc/diag.hip)."""
+        v = C.c_double(0)
+        _l.check(self._lib.mi355_probe_hbm_read(self._h, int(megabytes), C.byref(v)))
+        return v.value
+
     def get_timing(self):
         """(ms in the diff/threshold/pack kernel, ms in pack+scan+gather, launches) since reset."""
         a, b, n = C.c_double(0), C.c_double(0), C.c_int(0)

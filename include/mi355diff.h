@@ -73,7 +73,7 @@ typedef struct mi355_config {
  * arguments).  A binding checks mi355_abi_version() == MI355_ABI_VERSION when it loads the library
  * (cudavideostream_amd/lib.py, compat/include/group.hpp do).
  *   3  round 3: mi355_group_gather gained member_capacity (6th argument)
- *   4  round 4: + mi355_abi_version, mi355_probe_clock (additions only) */
+ *   4  round 4: + mi355_abi_version, mi355_probe_clock, mi355_probe_hbm_read (additions only) */
 #define MI355_ABI_VERSION 4
 int mi355_abi_version(void);
 
@@ -345,6 +345,9 @@ int mi355_reset_timing(mi355_core *core);
  * (csrc/diag.hip).  The diff path is bound by instruction issue, so its frames/s follow this clock; boards differ.
  * Runs on the core's stream and returns after it has finished; not part of any data path. */
 int mi355_probe_clock(mi355_core *core, int milliseconds, double *shader_mhz);
+/* Diagnostics: GB/s of a plain streaming read of a temporary `megabytes` MB buffer (64..16384; best of three passes):
+ * what this board's memory system gives a read-only kernel.  The pack kernel is bound by it; boards differ by ~7 %. */
+int mi355_probe_hbm_read(mi355_core *core, size_t megabytes, double *gbps);
 
 #ifdef __cplusplus
 }

@@ -268,12 +268,14 @@ int main(int argc, char **argv) {
     MI_OK(mi355_get_kernel_timing(core, &k_pack, &k_scan, &k_exp, &kl));
     double mhz = 0;
     if (!getenv("DIFFBENCH_NO_CLOCK")) MI_OK(mi355_probe_clock(core, 50, &mhz));   // right behind the timed region: the chip is warm
+    double hbm = 0;
+    if (getenv("DIFFBENCH_HBM_PROBE")) MI_OK(mi355_probe_hbm_read(core, 2048, &hbm));
     printf("{\"harness\": \"diffbench\", \"mode\": \"%s\", \"width\": %d, \"height\": %d, \"batch\": %d, \"steps\": %d, "
            "\"frames_per_s\": %.1f, \"ms_per_step\": %.4f, \"frac\": %.4f, \"kernel_ms\": %.4f, \"all_kernels_ms\": %.4f, \"kernels_us\": [%.1f, %.1f, %.1f], "
-           "\"changed_bytes_per_frame\": %.1f, \"achieved_gbps\": %.1f, \"shader_mhz\": %.0f, \"workspace_bytes\": %zu}\n",
+           "\"changed_bytes_per_frame\": %.1f, \"achieved_gbps\": %.1f, \"shader_mhz\": %.0f, \"hbm_read_probe_gbps\": %.0f, \"workspace_bytes\": %zu}\n",
            pairs ? "pairs" : "stream", W, H, B, K, (double)B * K / sec, sec / K * 1e3, alg / (sec / K) / 8e12, pack_ms, ms_total / (launches ? launches : 1),
            k_pack / (kl ? kl : 1) * 1e3, k_scan / (kl ? kl : 1) * 1e3, k_exp / (kl ? kl : 1) * 1e3,
-           p / B, alg / (pack_ms * 1e-3) / 1e9, mhz, mi355_workspace_bytes(core));
+           p / B, alg / (pack_ms * 1e-3) / 1e9, mhz, hbm, mi355_workspace_bytes(core));
     mi355_destroy(core);
     return 0;
 }
