@@ -53,6 +53,15 @@ __global__ void k_webcam_frame(uint8_t *out, int t, int width, int height, uint3
     out[idx] = (uint8_t)(val < 0 ? 0 : val > 255 ? 255 : val);
 }
 
+// synth.py refrand_frame(n, seed): S0, bytes uniform on 0..254 (the generator of tests/algorithms_benchmarks.cu:4-10);
+// flip != 0: the same frame with bit 7 of every byte flipped (P = N against the unflipped one)
+__global__ void k_refrand_frame(uint8_t *out, uint32_t n, uint32_t seed, int flip) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const uint32_t v = hash32(hash32(idx) + seed * 0x85EBCA6Bu) % 255u;
+    out[idx] = (uint8_t)(flip ? v ^ 0x80u : v);
+}
+
 // --corun valu|mem|lds: a background kernel of single-wave workgroups on a stream of its own while the timed batches run
 // (what does the pack kernel share with a co-runner: issue slots or the memory system?).  Experiment only.
 __global__ __launch_bounds__(64) void k_corun_valu(uint32_t *out, int iters) {
@@ -80,6 +89,7 @@ int main(int argc, char **argv) {
     uint32_t seed = 21;
     bool pairs = false, filters = false, digest = false;
     const char *corun = nullptr; int corun_blocks = 2048;
+    const char *regime = nullptr;   // --regime s0|flip|static: pairs of the dense / static regimes (tools/bench_regimes.py's inputs)
     for (int i = 1; i < argc; i++) {
         auto next = [&](int &v) { if (i + 1 < argc) v = atoi(argv[++i]); };
         if (!strcmp(argv[i], "--width")) next(W);
@@ -94,6 +104,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--filters")) filters = true;
         else if (!strcmp(argv[i], "--digest")) digest = true;
         else if (!strcmp(argv[i], "--corun") && i + 1 < argc) corun = argv[++i];
+        else if (!strcmp(argv[i], "--regime") && i + 1 < argc) { regime = argv[++i]; pairs = true; }
         else if (!strcmp(argv[i], "--corun-blocks")) next(corun_blocks);
     }
     const size_t n = (size_t)3 * W * H;
@@ -215,14 +226,27 @@ int main(int argc, char **argv) {
     HIP_OK(hipMemcpy(h_base.data(), d_base, n, hipMemcpyDeviceToHost));
     MI_OK(mi355_set_state(core, h_base.data()));
 
-    const size_t cap = (size_t)B * n / 8 > (1u << 20) ? (size_t)B * n / 8 : (1u << 20);
+    uint8_t *d_cur = d_frames + n, *d_prev = d_frames;   // pairs: consecutive frames of the stream
+    if (regime) {   // cur = refrand(100 + B + t) (s0) / prev ^ 0x80 (flip) / prev (static), prev = refrand(100 + t)
+        uint8_t *d_r;
+        HIP_OK(hipMalloc((void **)&d_r, n * (size_t)(2 * B)));
+        for (int t = 0; t < B; t++) {
+            hipLaunchKernelGGL(k_refrand_frame, g, b, 0, 0, d_r + (size_t)t * n, (uint32_t)n, 100u + t, 0);
+            const bool s0 = !strcmp(regime, "s0");
+            hipLaunchKernelGGL(k_refrand_frame, g, b, 0, 0, d_r + (size_t)(B + t) * n, (uint32_t)n, s0 ? 100u + B + t : 100u + t,
+                               !strcmp(regime, "flip") ? 1 : 0);
+        }
+        HIP_OK(hipDeviceSynchronize());
+        d_prev = d_r; d_cur = d_r + (size_t)B * n;
+    }
+    const size_t cap = regime ? (size_t)B * n : ((size_t)B * n / 8 > (1u << 20) ? (size_t)B * n / 8 : (1u << 20));
     uint32_t *d_off; int32_t *d_xs; uint8_t *d_df;
     HIP_OK(hipMalloc((void **)&d_off, sizeof(uint32_t) * (B + 1)));
     HIP_OK(hipMalloc((void **)&d_xs, sizeof(int32_t) * cap));
     HIP_OK(hipMalloc((void **)&d_df, cap));
 
     auto step = [&]() {
-        if (pairs) MI_OK(mi355_diff_pairs_batch(core, d_frames + n, d_frames, n, B, d_off, d_xs, d_df, cap));
+        if (pairs) MI_OK(mi355_diff_pairs_batch(core, d_cur, d_prev, n, B, d_off, d_xs, d_df, cap));
         else MI_OK(mi355_diff_stream_batch(core, d_frames, n, B, d_off, d_xs, d_df, cap));
     };
     for (int i = 0; i < WU; i++) step();
