@@ -48,6 +48,11 @@ namespace mi355 {
 #ifndef MI355_K1PRIO
 #define MI355_K1PRIO 0
 #endif
+// Dense tiles (every lane of a (frame, tile) with two or more flagged bytes) append records only, no codes: a fifth less
+// log for the synthetic worst cases (refrand pairs, P = N); the expander rebuilds the maps from the records (record_map16).
+#ifndef MI355_RECORD_ONLY
+#define MI355_RECORD_ONLY 1
+#endif
 #ifndef MI355_K1_PAD     // timing builds: this many extra vector instructions per frame and tile (what does an instruction cost?)
 #define MI355_K1_PAD 0
 #endif
@@ -145,10 +150,22 @@ __device__ __forceinline__ uint32_t emit_step(const uint32_t (&dm)[4], uint32_t 
     pc = lp.ptrC;
     pm = lp.ptrM;
     if (nc == 0u) return 0u;   // wave-uniform: a still tile appends nothing (and issues no store)
-    if (nc > lp.roomC) { lp.ptrC += lp.roomC * 4u + jump; lp.roomC = 256u; }
     if (nm > lp.roomM) { lp.ptrM += lp.roomM * 16u + jump; lp.roomM = 64u; }
-    pc = lp.ptrC;
     pm = lp.ptrM;
+#if MI355_RECORD_ONLY
+    if (nm == 64u) {   // wave-uniform: a DENSE tile (all 64 lanes carry two or more flagged bytes) appends records only: a
+                       // lane's record is record `lane`, and its map is the record's non-zero bytes (|df| > T >= 0 is never 0)
+#if MI355_ABLATE == 0
+        const u32x4 v = {dm[0], dm[1], dm[2], dm[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(v, lg.recs, pm + rankM * 16u, 0, 0);
+#endif
+        lp.ptrM += 64u * 16u;
+        lp.roomM -= 64u;
+        return 64u | (64u << 16);
+    }
+#endif
+    if (nc > lp.roomC) { lp.ptrC += lp.roomC * 4u + jump; lp.roomC = 256u; }
+    pc = lp.ptrC;
     // a lane with one flagged byte: the byte sum of its masked differences IS that byte
     const uint32_t one = __builtin_amdgcn_sad_u8((dm[0] | dm[1]) | (dm[2] | dm[3]), 0u, 0u);
     const uint32_t code = m16 | ((multi ? rankM : one) << 16) | lane24;
@@ -801,15 +818,19 @@ __device__ __forceinline__ void expand_tiles(const ExpandArgs &a, const uint4 *t
                                              uint32_t dst0, uint8_t *w_xs, uint8_t *w_df, size_t w_room) {
     const __amdgpu_buffer_rsrc_t codes = make_rsrc(a.codes, a.codes_bytes), recs = make_rsrc(a.rec, a.rec_bytes);
     // loads beyond the item (i >= 16) or without a candidate carry an offset outside the buffer: they return 0 and read nothing
+    // tinfo[i].w = candidates | multi-byte lanes << 16.  A DENSE tile (64 multi-byte lanes) has records only (k_diff_pack,
+    // MI355_RECORD_ONLY): no codes are loaded, record `lane` is the lane's, its map are the record's non-zero bytes
     auto load_code = [&](uint32_t i) {
         const uint4 ti = tinfo[i & (kWTiles - 1u)];
-        return __builtin_amdgcn_raw_buffer_load_b32(codes, (i < kWTiles && lane < ti.w) ? ti.x + 4u * lane : kOOB, 0, 0);
+        const bool dense = MI355_RECORD_ONLY && (ti.w >> 16) == 64u;
+        return __builtin_amdgcn_raw_buffer_load_b32(codes, (i < kWTiles && !dense && lane < (ti.w & 0xffffu)) ? ti.x + 4u * lane : kOOB, 0, 0);
     };
     auto load_rec = [&](uint32_t i, uint32_t c) {
         const uint4 ti = tinfo[i & (kWTiles - 1u)];
         const uint32_t m16 = c & 0xffffu;
-        // a tile with all bytes flagged: record `lane`; otherwise the record of a lane with two or more flagged bytes
-        const uint32_t off = ti.z == kTileBytes ? ti.y + 16u * lane : ((m16 & (m16 - 1u)) ? ti.y + 16u * ((c >> 16) & 0xffu) : kOOB);
+        const bool dense = MI355_RECORD_ONLY ? (ti.w >> 16) == 64u : ti.z == kTileBytes;
+        // a dense tile: record `lane`; otherwise the record of a lane with two or more flagged bytes
+        const uint32_t off = dense ? ti.y + 16u * lane : ((m16 & (m16 - 1u)) ? ti.y + 16u * ((c >> 16) & 0xffu) : kOOB);
         return __builtin_amdgcn_raw_buffer_load_b128(recs, i < kWTiles ? off : kOOB, 0, 0);
     };
     uint32_t carry = 0, flushed = 0;   // entries of the item expanded so far / already stored (wave-uniform)
@@ -820,7 +841,9 @@ __device__ __forceinline__ void expand_tiles(const ExpandArgs &a, const uint4 *t
         const uint32_t c2 = load_code(i + 2u);
         const u32x4 r1 = load_rec(i + 1u, c1);
         const uint4 ti = tinfo[i];
-        const uint32_t nc = (uint32_t)__builtin_amdgcn_readfirstlane((int)ti.w), bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)ti.z);
+        const uint32_t ncm = (uint32_t)__builtin_amdgcn_readfirstlane((int)ti.w), bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)ti.z);
+        const uint32_t nc = ncm & 0xffffu;
+        const bool dense = MI355_RECORD_ONLY && (ncm >> 16) == 64u;   // records only, no codes
         if (nc != 0u) {
             const bool full = bytes == kTileBytes;   // every byte of the tile flagged: its 64 records are the difference bytes
             if (full || carry - flushed + bytes > kWStage) {   // make room (a full tile goes straight out: empty the stage first)
@@ -841,10 +864,11 @@ __device__ __forceinline__ void expand_tiles(const ExpandArgs &a, const uint4 *t
                 *reinterpret_cast<U32x4A1 *>(dfp + 16 * lane) = U32x4A1{r0.x, r0.y, r0.z, r0.w};
                 flushed = carry + kTileBytes;
             } else {
-                const uint32_t m16 = c0 & 0xffffu;
+                const uint4 r = make_uint4(r0.x, r0.y, r0.z, r0.w);
+                const uint32_t m16 = dense ? record_map16(r) : (c0 & 0xffffu);
                 const uint32_t cnt = (uint32_t)__builtin_popcount(m16);
                 const uint32_t e = carry - flushed + (uint32_t)wave_inclusive_scan((int)cnt) - cnt;
-                const uint32_t src16 = (i << 10) + ((c0 >> 20) & 0x3f0u);
+                const uint32_t src16 = (i << 10) + (dense ? lane * 16u : ((c0 >> 20) & 0x3f0u));
                 if (cnt == 1u) stage[e] = ((src16 + (uint32_t)__builtin_ctz(m16)) << 8) | ((c0 >> 16) & 0xffu);   // kernels.cu:314-315
                 const bool multi = cnt > 1u;
                 if (__ballot(multi)) walk_records(multi ? m16 : 0u, e, src16, make_uint4(r0.x, r0.y, r0.z, r0.w), stage, lane);   // wave-uniform
@@ -920,10 +944,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // two neighbouring tiles share a round of 64 lanes; the even tile's lane learns the odd tile's facts
     const uint32_t nc_b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nc, 0x101 /* row_shl:1 */, 0xf, 0xf, true);
     const bool even = (lane & 1u) == 0u;
-    const bool pairs = __ballot(even && nc + nc_b > 64u) == 0 && nent <= kFStage && (tot >> 16) <= kFList;   // wave-uniform
+    // (a dense tile -- 64 multi-byte lanes -- has no codes: the tile path's)
+    const bool pairs = __ballot((even && nc + nc_b > 64u) || (m.w >> 16) == 64u) == 0 && nent <= kFStage && (tot >> 16) <= kFList;   // wave-uniform
     if (!pairs) {
         uint4 *const s_tinfo = reinterpret_cast<uint4 *>(s_list);
-        if (lane < kWTiles) s_tinfo[lane] = make_uint4(m.x, m.y, m.z, nc);
+        if (lane < kWTiles) s_tinfo[lane] = make_uint4(m.x, m.y, m.z, m.w);   // .w = candidates | multi-byte lanes << 16
         lds_handoff();
         expand_tiles<WIRE>(a, s_tinfo, s_stage, lane, xs0, dst0, w_xs, w_df, w_room);
         return;
