@@ -367,7 +367,30 @@ int setup_pipeline(mi355_core *c) {
     ok = ok && hipMalloc((void **)&s1.groff, T * expand_groups(c->ntiles) * 16) == hipSuccess;
     ok = ok && hipMalloc((void **)&s1.totals, (T + 1) * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(s1.totals, 0, (T + 1) * sizeof(uint32_t)) == hipSuccess;   // the scan kernel's ticket
-    if (side_prio) {
+    // Experiment (MI355_CU_SPLIT=n, 1..31): the side stream on n CUs of every XCD, the core's stream on the others
+    // (hipExtStreamCreateWithCUMask; mask bit i = CU i / 8 of XCD i % 8): the expansion and the pack kernel then share the
+    // memory system only, not each other's issue slots.
+    int cu_split = 0;
+    if (const char *b = getenv("MI355_CU_SPLIT")) cu_split = atoi(b);
+    if (cu_split > 0 && cu_split < 32) {
+        uint32_t side_mask[8], main_mask[8];
+        for (int w = 0; w < 8; w++) {
+            side_mask[w] = 0; main_mask[w] = 0;
+            for (int bit = 0; bit < 32; bit++) {
+                const int i = w * 32 + bit;
+                if (i < 8 * cu_split) side_mask[w] |= 1u << bit; else main_mask[w] |= 1u << bit;
+            }
+        }
+        hipStream_t m = nullptr;
+        ok = ok && hipExtStreamCreateWithCUMask(&c->side, 8, side_mask) == hipSuccess;
+        ok = ok && hipExtStreamCreateWithCUMask(&m, 8, main_mask) == hipSuccess;
+        if (ok) {   // the core moves to the masked stream (nothing is queued on the old one at this point: first batch call)
+            (void)hipStreamSynchronize(c->own_stream);
+            (void)hipStreamDestroy(c->own_stream);
+            c->own_stream = m;
+            c->stream = m;
+        }
+    } else if (side_prio) {
         int lo = 0, hi = 0;
         ok = ok && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi) == hipSuccess;

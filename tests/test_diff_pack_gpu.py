@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 from gpu_util import DEV, CUDACore, oracle_pairs, run_stream, to_dev  # noqa: E402
+from gpu_util import _CUDACore as RawCore  # noqa: E402  (the product class without the harness's call-time synchronisation)
 
 
 def check_stream(po, core, base, frames, thr=20, **kw):
@@ -397,9 +398,8 @@ def test_back_to_back_batches_without_synchronisation(po):
              torch.zeros(T * n, dtype=torch.uint8, device=DEV)) for _ in range(K)]
     with CUDACore(w, h, max_batch=T, sample_mat_data=base) as core:
         torch.cuda.synchronize()
-        bound = object.__getattribute__(core, "diff_stream_batch")   # no host synchronisation between the calls
-        for k in range(K):
-            bound(d_fr[k * T:(k + 1) * T], T, *outs[k], T * n)
+        for k in range(K):   # the product class's method, not the harness's wrapper: no host synchronisation between the calls
+            RawCore.diff_stream_batch(core, d_fr[k * T:(k + 1) * T], T, *outs[k], T * n)
         core.synchronize()
         assert np.array_equal(core.get_state(), est)
     # oracle: per-frame entries of the whole sequence, cut into the batches
@@ -415,6 +415,53 @@ def test_back_to_back_batches_without_synchronisation(po):
         at += tot
 
 
+def test_pipelined_1080p_batches_equal_the_sequential_path(po):
+    """Full-size overlap: five batches of 65 (odd) 1080p frames queued back to back on the core's own stream -- the
+    expansion of batch k runs beside the pack kernel of batch k + 1, two sets of logs in turn, the pack kernel on its
+    pipelined grid --, the last two in the wire form; against the same sequence on a caller's stream (never pipelined),
+    byte for byte: offsets, indices, differences, wire bytes and the final state; batch 0 also against the oracle."""
+    w, h, T, K = 1920, 1080, 65, 5
+    n = 3 * w * h
+    base, frames = synth.webcam_stream(T * K, w, h, seed=77, device=DEV)
+    cap = T * n // 8
+    wire_cap = 4 * T + 5 * cap
+
+    def run(pipelined):
+        outs = [(torch.zeros(T + 1, dtype=torch.int32, device=DEV), torch.full((cap,), -7, dtype=torch.int32, device=DEV),
+                 torch.zeros(cap, dtype=torch.uint8, device=DEV)) for _ in range(K - 2)]
+        wires = [(torch.zeros(T + 1, dtype=torch.int32, device=DEV), torch.zeros(wire_cap, dtype=torch.uint8, device=DEV)) for _ in range(2)]
+        with CUDACore(w, h, max_batch=T, sample_mat_data=base.cpu().numpy()) as core:
+            if not pipelined:
+                core.use_torch_stream()
+            torch.cuda.synchronize()
+            for k in range(K - 2):
+                RawCore.diff_stream_batch(core, frames[k * T:(k + 1) * T], T, *outs[k], cap)
+            for j in range(2):
+                k = K - 2 + j
+                RawCore.diff_stream_wire_batch(core, frames[k * T:(k + 1) * T], T, wires[j][0], wires[j][1], wire_cap)
+            core.synchronize()
+            torch.cuda.synchronize()
+            state = core.get_state()
+        res = []
+        for o, x, d in outs:
+            off = o.cpu().numpy().view(np.uint32)
+            assert int(off[-1]) <= cap
+            res.append((off, x[:int(off[-1])].cpu().numpy(), d[:int(off[-1])].cpu().numpy()))
+        for o, wbuf in wires:
+            off = o.cpu().numpy().view(np.uint32)
+            res.append((off, wbuf[:4 * T + 5 * int(off[-1])].cpu().numpy()))
+        return res, state
+
+    got, st_p = run(True)
+    want, st_s = run(False)
+    assert np.array_equal(st_p, st_s)
+    for k in range(K):
+        for a, b in zip(got[k], want[k]):
+            assert np.array_equal(a, b), k
+    eo, exs, edf, _ = po.diff_stream(frames[:T].cpu().numpy(), base.cpu().numpy())
+    assert np.array_equal(got[0][0], eo) and np.array_equal(got[0][1], exs) and np.array_equal(got[0][2], edf)
+
+
 def test_pipelined_batches_then_other_entry_points(po):
     """What follows a pipelined batch on the same core -- here the red motion map built from the batch's packed
     stream, queued at once -- sees the batch complete (every entry point joins the side stream first); the client's
@@ -427,8 +474,8 @@ def test_pipelined_batches_then_other_entry_points(po):
     d_fr = to_dev(frames)
     with CUDACore(w, h, max_batch=T, sample_mat_data=base) as core, CUDACore(w, h, max_batch=T, sample_mat_data=base) as client:
         torch.cuda.synchronize()
-        stream_batch = object.__getattribute__(core, "diff_stream_batch")
-        red_batch = object.__getattribute__(core, "red_stream_batch")
+        stream_batch = lambda *a, **kw: RawCore.diff_stream_batch(core, *a, **kw)   # noqa: E731  (no host synchronisation in between)
+        red_batch = lambda *a, **kw: RawCore.red_stream_batch(core, *a, **kw)      # noqa: E731
         outs, maps = [], []
         for k in range(3):
             d_off = torch.zeros(T + 1, dtype=torch.int32, device=DEV)
