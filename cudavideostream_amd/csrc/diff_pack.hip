@@ -356,7 +356,18 @@ __global__ __launch_bounds__(256) void k_diff_pack(const PackArgs a) {
     const int lane = threadIdx.x & 63;
     // one tile per wave when the grid covers the frame (the default); a smaller grid walks the tiles with its stride
     // (pipelined batches leave wave slots to the expansion of the batch before, core.hip)
-    for (uint32_t tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); tile < a.ntiles; tile += gridDim.x * kWavesPerBlock) {
+    // The wave's number is the same in all its lanes, but the compiler cannot know that of threadIdx.x >> 6: without the
+    // readfirstlane everything derived from the tile -- the log positions above all -- lived in VECTOR registers and was
+    // updated with v_cndmask / v_add / v_mov (12 vector instructions per frame of the 114; MI355_K1_UNIFORM_TILE=0 restores that).
+#ifndef MI355_K1_UNIFORM_TILE
+#define MI355_K1_UNIFORM_TILE 1
+#endif
+#if MI355_K1_UNIFORM_TILE
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
+    const uint32_t wave = threadIdx.x >> 6;
+#endif
+    for (uint32_t tile = blockIdx.x * kWavesPerBlock + wave; tile < a.ntiles; tile += gridDim.x * kWavesPerBlock) {
         const uint32_t tile_off = tile * kTileBytes;
         const uint32_t byte_off = tile_off + (uint32_t)lane * 16u;
         // wave-uniform choice: every lane of a full, aligned tile takes the vector path
