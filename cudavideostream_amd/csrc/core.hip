@@ -118,13 +118,21 @@ struct mi355_core {
         hipEvent_t packed = nullptr, expanded = nullptr;   // pack kernel done (main) / expansion done (side)
         bool in_use = false;                                // `expanded` has been recorded at least once
     };
-    LogSet set[2];
+    static constexpr int kMaxSets = 3;
+    LogSet set[kMaxSets];
+    int nsets = 2;                    // MI355_LOGSETS=3: a third set (experiment)
     int flip = 0;
     hipStream_t side = nullptr;
     hipEvent_t side_done = nullptr;   // == the `expanded` event of the last pipelined batch, or null: nothing pending
     bool pipeline_ok = true;          // false: MI355_PIPELINE=0, or the second set could not be allocated
     uint32_t k1_blocks = 0;           // pipelined batches: workgroups of the pack kernel (0 = one tile per wave)
     bool scan_on_main = false;        // pipelined batches: the index kernel runs on the core's stream, between two pack kernels
+    // pipelined batches packed by TWO launches (tiles [0, split) on the core's stream, the rest on `main2`): the two chains
+    // of pack kernels drift apart, each one's kernel boundary (L2 write-back, event packets: 21-25 us) falls into the other's
+    // kernel.  split_pct = 0: one launch.
+    int split_pct = 50;
+    hipStream_t main2 = nullptr;
+    hipEvent_t packed2[3] = {nullptr, nullptr, nullptr};
 
     // timing: ring of event sets {before pack, after pack, before scan, after scan, after expand}, harvested lazily
     // so that timed batches still queue back to back
@@ -356,17 +364,24 @@ int setup_pipeline(mi355_core *c) {
     }
     if (const char *b = getenv("MI355_K1_BLOCKS")) c->k1_blocks = (uint32_t)atoi(b);   // tuning knob (tools/, profiles/)
     if (const char *b = getenv("MI355_SCAN_MAIN")) c->scan_on_main = b[0] == '1';
+    if (const char *b = getenv("MI355_SPLIT")) c->split_pct = atoi(b);
+    if (c->split_pct < 5 || c->split_pct > 95) c->split_pct = 0;
+    if (const char *b = getenv("MI355_LOGSETS")) c->nsets = atoi(b) == 3 ? 3 : 2;
     int side_prio = 0;
     if (const char *b = getenv("MI355_SIDE_PRIO")) side_prio = atoi(b);   // 1: the side stream gets the highest stream priority
     const size_t T = (size_t)c->cfg.max_batch, W = c->ntiles;
-    mi355_core::LogSet &s0 = c->set[0], &s1 = c->set[1];
+    mi355_core::LogSet &s0 = c->set[0];
     s0.rec = c->rec; s0.codes = c->codes; s0.meta = c->meta; s0.groff = c->groff; s0.totals = c->totals;
-    bool ok = hipMalloc((void **)&s1.rec, T * W * 1024) == hipSuccess;
-    ok = ok && hipMalloc((void **)&s1.codes, code_chunks(T) * W * 1024) == hipSuccess;
-    ok = ok && hipMalloc((void **)&s1.meta, T * W * 16) == hipSuccess;
-    ok = ok && hipMalloc((void **)&s1.groff, T * expand_groups(c->ntiles) * 16) == hipSuccess;
-    ok = ok && hipMalloc((void **)&s1.totals, (T + 1) * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipMemset(s1.totals, 0, (T + 1) * sizeof(uint32_t)) == hipSuccess;   // the scan kernel's ticket
+    bool ok = true;
+    for (int i = 1; i < c->nsets; i++) {
+        mi355_core::LogSet &s1 = c->set[i];
+        ok = ok && hipMalloc((void **)&s1.rec, T * W * 1024) == hipSuccess;
+        ok = ok && hipMalloc((void **)&s1.codes, code_chunks(T) * W * 1024) == hipSuccess;
+        ok = ok && hipMalloc((void **)&s1.meta, T * W * 16) == hipSuccess;
+        ok = ok && hipMalloc((void **)&s1.groff, T * expand_groups(c->ntiles) * 16) == hipSuccess;
+        ok = ok && hipMalloc((void **)&s1.totals, (T + 1) * sizeof(uint32_t)) == hipSuccess;
+        ok = ok && hipMemset(s1.totals, 0, (T + 1) * sizeof(uint32_t)) == hipSuccess;   // the scan kernel's ticket
+    }
     // Experiment (MI355_CU_SPLIT=n, 1..31): the side stream on n CUs of every XCD, the core's stream on the others
     // (hipExtStreamCreateWithCUMask; mask bit i = CU i / 8 of XCD i % 8): the expansion and the pack kernel then share the
     // memory system only, not each other's issue slots.
@@ -397,7 +412,11 @@ int setup_pipeline(mi355_core *c) {
     } else {
         ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
     }
-    for (int i = 0; i < 2 && ok; i++) {
+    if (c->split_pct) {
+        ok = ok && hipStreamCreateWithFlags(&c->main2, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; i < c->nsets && ok; i++) ok = hipEventCreateWithFlags(&c->packed2[i], hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
+    }
+    for (int i = 0; i < c->nsets && ok; i++) {
         // device-scope release: these events only order kernels of this device against each other.  An event's default
         // is a SYSTEM-scope fence when it is recorded (caches written back and invalidated for the host's benefit),
         // which every batch paid twice on the core's stream between two pack kernels
@@ -407,14 +426,18 @@ int setup_pipeline(mi355_core *c) {
     }
     if (!ok) {   // not an error: the batches then run one after the other, as with a caller's stream
         (void)hipGetLastError();
-        void *ptrs[] = {s1.rec, s1.codes, s1.meta, s1.groff, s1.totals};
-        for (void *p : ptrs) if (p) (void)hipFree(p);
-        s1 = mi355_core::LogSet{};
+        for (int i = 1; i < mi355_core::kMaxSets; i++) {
+            mi355_core::LogSet &s1 = c->set[i];
+            void *ptrs[] = {s1.rec, s1.codes, s1.meta, s1.groff, s1.totals};
+            for (void *p : ptrs) if (p) (void)hipFree(p);
+            s1 = mi355_core::LogSet{};
+        }
         if (c->side) { (void)hipStreamDestroy(c->side); c->side = nullptr; }
+        if (c->main2) { (void)hipStreamDestroy(c->main2); c->main2 = nullptr; }
         c->pipeline_ok = false;
         return MI355_OK;
     }
-    c->workspace += T * W * 1024 + code_chunks(T) * W * 1024 + T * W * 16 + T * expand_groups(c->ntiles) * 16 + (T + 1) * 4;
+    c->workspace += (size_t)(c->nsets - 1) * (T * W * 1024 + code_chunks(T) * W * 1024 + T * W * 16 + T * expand_groups(c->ntiles) * 16 + (T + 1) * 4);
     return MI355_OK;
 }
 
@@ -494,6 +517,8 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     a.nframes = nframes;
     a.thr = c->cfg.threshold;
     a.ntiles = c->ntiles;
+    a.tile_begin = 0;
+    a.tile_end = c->ntiles;
     a.rec = ls.rec;
     a.codes = ls.codes;
     a.codes_bytes = (uint32_t)(code_chunks((size_t)c->cfg.max_batch) * c->ntiles * 1024u);
@@ -503,13 +528,30 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     // the vector path of the pack kernel: 16-byte aligned operands, and a group of four frames within reach of one
     // buffer descriptor's 32-bit offsets (diff_pack.hip, Group::load_desc)
     const bool aligned = (((uintptr_t)d_cur | (uintptr_t)d_prev | stride) & 15u) == 0 && 3 * (uint64_t)stride + c->n < (1ull << 32);
-    HIP_TRY(launch_diff_pack(a, pair, aligned, pipelined ? c->k1_blocks : 0u, c->stream));
+    const bool split = pipelined && c->split_pct && c->main2 && c->ntiles >= 64;
+    if (split) {
+        // first part on the core's stream, second part on main2 (which also has to see the log set free); each part
+        // takes its share of the pipelined grid
+        const uint32_t cut = (uint32_t)((uint64_t)c->ntiles * (uint32_t)c->split_pct / 100u) & ~3u;
+        if (ls.in_use) HIP_TRY(hipStreamWaitEvent(c->main2, ls.expanded, 0));
+        PackArgs a1 = a, a2 = a;
+        a1.tile_end = cut;
+        a2.tile_begin = cut;
+        const uint32_t b1 = c->k1_blocks ? (uint32_t)((uint64_t)c->k1_blocks * (uint32_t)c->split_pct / 100u) : 0u;
+        HIP_TRY(launch_diff_pack(a1, pair, aligned, b1, c->stream));
+        HIP_TRY(launch_diff_pack(a2, pair, aligned, c->k1_blocks ? c->k1_blocks - b1 : 0u, c->main2));
+        HIP_TRY(hipEventRecord(c->packed2[c->flip], c->main2));
+        HIP_TRY(hipStreamWaitEvent(tail, c->packed2[c->flip], 0));
+    } else {
+        HIP_TRY(launch_diff_pack(a, pair, aligned, pipelined ? c->k1_blocks : 0u, c->stream));
+    }
     if (tev) HIP_TRY(hipEventRecord(tev[1], c->stream));
     // The index kernel is short (12 us alone) and gates the expansion: behind the next batch's pack kernel on the side
     // stream it waits for wave slots and for memory round trips that take ten times as long there; on the core's
     // stream it runs before the next pack kernel starts.
     const bool scan_main = pipelined && c->scan_on_main;
     hipStream_t ss = scan_main ? c->stream : tail;
+    if (scan_main && split) HIP_TRY(hipStreamWaitEvent(c->stream, c->packed2[c->flip], 0));   // the index reads both parts' meta words
     if (pipelined && !scan_main) {
         HIP_TRY(hipEventRecord(ls.packed, c->stream));
         HIP_TRY(hipStreamWaitEvent(tail, ls.packed, 0));
@@ -544,7 +586,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
         HIP_TRY(hipEventRecord(ls.expanded, tail));
         ls.in_use = true;
         c->side_done = ls.expanded;
-        c->flip ^= 1;
+        c->flip = (c->flip + 1) % c->nsets;
     }
     return MI355_OK;
 }
@@ -641,14 +683,18 @@ void mi355_destroy(mi355_core *c) {
     if (c->side) (void)hipStreamSynchronize(c->side);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     {
-        mi355_core::LogSet &s1 = c->set[1];
-        void *more[] = {s1.rec, s1.codes, s1.meta, s1.groff, s1.totals};
-        for (void *p : more) if (p) (void)hipFree(p);
+        for (int i = 1; i < mi355_core::kMaxSets; i++) {
+            mi355_core::LogSet &s1 = c->set[i];
+            void *more[] = {s1.rec, s1.codes, s1.meta, s1.groff, s1.totals};
+            for (void *p : more) if (p) (void)hipFree(p);
+        }
         for (auto &ls : c->set) {
             if (ls.packed) (void)hipEventDestroy(ls.packed);
             if (ls.expanded) (void)hipEventDestroy(ls.expanded);
         }
         if (c->side) (void)hipStreamDestroy(c->side);
+        if (c->main2) { (void)hipStreamSynchronize(c->main2); (void)hipStreamDestroy(c->main2); }
+        for (auto &e : c->packed2) if (e) (void)hipEventDestroy(e);
     }
     void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->codes, c->meta, c->groff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
                     c->lut, c->glyphs, c->kxk, c->gray1, c->red_bounds, c->f_wgsum, c->f_sync, c->f_spill, c->f_ovf, c->f_ready, c->c_desc, c->c_status};

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void k_diff_pack(const PackArgs a) {
 #else
     const uint32_t wave = threadIdx.x >> 6;
 #endif
-    for (uint32_t tile = blockIdx.x * kWavesPerBlock + wave; tile < a.ntiles; tile += gridDim.x * kWavesPerBlock) {
+    for (uint32_t tile = a.tile_begin + blockIdx.x * kWavesPerBlock + wave; tile < a.tile_end; tile += gridDim.x * kWavesPerBlock) {
         const uint32_t tile_off = tile * kTileBytes;
         const uint32_t byte_off = tile_off + (uint32_t)lane * 16u;
         // wave-uniform choice: every lane of a full, aligned tile takes the vector path
@@ -382,8 +382,9 @@ __global__ __launch_bounds__(256) void k_diff_pack(const PackArgs a) {
 
 hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, uint32_t max_blocks, hipStream_t s) {
     const dim3 block(64 * kWavesPerBlock);
-    uint32_t blocks = (a.ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    uint32_t blocks = (a.tile_end - a.tile_begin + kWavesPerBlock - 1) / kWavesPerBlock;
     if (max_blocks && max_blocks < blocks) blocks = max_blocks;
+    if (blocks == 0) return hipSuccess;
     const dim3 grid(blocks);
     // thresholds of 128 and more (the reference's LR_THRESHOLDS is an unconstrained int, common.h:14) take the HIGH
     // form of the compare: another instantiation, the same instruction count

@@ -22,6 +22,8 @@ struct PackArgs {
     int32_t nframes;       // T
     int32_t thr;           // threshold
     uint32_t ntiles;       // W = ceil(n / 1024)
+    uint32_t tile_begin;   // this launch packs tiles [tile_begin, tile_end): the whole frame, or one part of it when a
+    uint32_t tile_end;     // pipelined batch is packed by two staggered launches (core.hip, MI355_SPLIT)
     uint32_t *codes;       // code log: T/4 chunks x W tiles x 256 codes (one per candidate lane)
     uint4 *rec;            // record log: T chunks x W tiles x 64 records of 16 masked diff bytes (multi-byte lanes)
     uint4 *meta;           // [T][W]: {code position, record position, flagged bytes, candidates | multi-byte lanes << 16}
