@@ -131,8 +131,10 @@ struct mi355_core {
     // of pack kernels drift apart, each one's kernel boundary (L2 write-back, event packets: 21-25 us) falls into the other's
     // kernel.  split_pct = 0: one launch.
     int split_pct = 50;
-    hipStream_t main2 = nullptr;
-    hipEvent_t packed2[3] = {nullptr, nullptr, nullptr};
+    static constexpr int kMaxParts = 4;
+    int parts = 2;                    // MI355_PARTS=3|4: more launches with equal shares (experiment)
+    hipStream_t main2[kMaxParts - 1] = {};
+    hipEvent_t packed2[kMaxParts - 1][3] = {};
 
     // timing: ring of event sets {before pack, after pack, before scan, after scan, after expand}, harvested lazily
     // so that timed batches still queue back to back
@@ -366,6 +368,8 @@ int setup_pipeline(mi355_core *c) {
     if (const char *b = getenv("MI355_SCAN_MAIN")) c->scan_on_main = b[0] == '1';
     if (const char *b = getenv("MI355_SPLIT")) c->split_pct = atoi(b);
     if (c->split_pct < 5 || c->split_pct > 95) c->split_pct = 0;
+    if (const char *b = getenv("MI355_PARTS")) c->parts = atoi(b);
+    if (c->parts < 2 || c->parts > mi355_core::kMaxParts) c->parts = 2;
     if (const char *b = getenv("MI355_LOGSETS")) c->nsets = atoi(b) == 3 ? 3 : 2;
     int side_prio = 0;
     if (const char *b = getenv("MI355_SIDE_PRIO")) side_prio = atoi(b);   // 1: the side stream gets the highest stream priority
@@ -413,8 +417,10 @@ int setup_pipeline(mi355_core *c) {
         ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
     }
     if (c->split_pct) {
-        ok = ok && hipStreamCreateWithFlags(&c->main2, hipStreamNonBlocking) == hipSuccess;
-        for (int i = 0; i < c->nsets && ok; i++) ok = hipEventCreateWithFlags(&c->packed2[i], hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
+        for (int p = 0; p + 1 < c->parts; p++) {
+            ok = ok && hipStreamCreateWithFlags(&c->main2[p], hipStreamNonBlocking) == hipSuccess;
+            for (int i = 0; i < c->nsets && ok; i++) ok = hipEventCreateWithFlags(&c->packed2[p][i], hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
+        }
     }
     for (int i = 0; i < c->nsets && ok; i++) {
         // device-scope release: these events only order kernels of this device against each other.  An event's default
@@ -433,7 +439,7 @@ int setup_pipeline(mi355_core *c) {
             s1 = mi355_core::LogSet{};
         }
         if (c->side) { (void)hipStreamDestroy(c->side); c->side = nullptr; }
-        if (c->main2) { (void)hipStreamDestroy(c->main2); c->main2 = nullptr; }
+        for (auto &m : c->main2) if (m) { (void)hipStreamDestroy(m); m = nullptr; }
         c->pipeline_ok = false;
         return MI355_OK;
     }
@@ -528,20 +534,33 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     // the vector path of the pack kernel: 16-byte aligned operands, and a group of four frames within reach of one
     // buffer descriptor's 32-bit offsets (diff_pack.hip, Group::load_desc)
     const bool aligned = (((uintptr_t)d_cur | (uintptr_t)d_prev | stride) & 15u) == 0 && 3 * (uint64_t)stride + c->n < (1ull << 32);
-    const bool split = pipelined && c->split_pct && c->main2 && c->ntiles >= 64;
+    const bool split = pipelined && c->split_pct && c->main2[0] && c->ntiles >= 64;
     if (split) {
-        // first part on the core's stream, second part on main2 (which also has to see the log set free); each part
-        // takes its share of the pipelined grid
-        const uint32_t cut = (uint32_t)((uint64_t)c->ntiles * (uint32_t)c->split_pct / 100u) & ~3u;
-        if (ls.in_use) HIP_TRY(hipStreamWaitEvent(c->main2, ls.expanded, 0));
-        PackArgs a1 = a, a2 = a;
-        a1.tile_end = cut;
-        a2.tile_begin = cut;
-        const uint32_t b1 = c->k1_blocks ? (uint32_t)((uint64_t)c->k1_blocks * (uint32_t)c->split_pct / 100u) : 0u;
-        HIP_TRY(launch_diff_pack(a1, pair, aligned, b1, c->stream));
-        HIP_TRY(launch_diff_pack(a2, pair, aligned, c->k1_blocks ? c->k1_blocks - b1 : 0u, c->main2));
-        HIP_TRY(hipEventRecord(c->packed2[c->flip], c->main2));
-        HIP_TRY(hipStreamWaitEvent(tail, c->packed2[c->flip], 0));
+        // first part on the core's stream, the others on streams of their own (which also have to see the log set free);
+        // each part takes its share of the pipelined grid
+        const uint32_t P = (uint32_t)c->parts;
+        uint32_t begin = 0, blocks_left = c->k1_blocks;
+        for (uint32_t p = 0; p < P; p++) {
+            const uint32_t share = P == 2 ? (p == 0 ? (uint32_t)c->split_pct : 100u) : (p + 1u) * 100u / P;   // cumulative per cent
+            const uint32_t end = p + 1u == P ? c->ntiles : (uint32_t)((uint64_t)c->ntiles * share / 100u) & ~3u;
+            uint32_t blocks = 0;
+            if (c->k1_blocks) {
+                blocks = p + 1u == P ? blocks_left : (uint32_t)((uint64_t)c->k1_blocks * (end - begin) / c->ntiles);
+                if (blocks == 0) blocks = 1;
+                blocks_left = blocks_left > blocks ? blocks_left - blocks : 1u;
+            }
+            PackArgs ap = a;
+            ap.tile_begin = begin;
+            ap.tile_end = end;
+            hipStream_t sp = p == 0 ? c->stream : c->main2[p - 1];
+            if (p > 0 && ls.in_use) HIP_TRY(hipStreamWaitEvent(sp, ls.expanded, 0));
+            HIP_TRY(launch_diff_pack(ap, pair, aligned, blocks, sp));
+            if (p > 0) {
+                HIP_TRY(hipEventRecord(c->packed2[p - 1][c->flip], sp));
+                HIP_TRY(hipStreamWaitEvent(tail, c->packed2[p - 1][c->flip], 0));
+            }
+            begin = end;
+        }
     } else {
         HIP_TRY(launch_diff_pack(a, pair, aligned, pipelined ? c->k1_blocks : 0u, c->stream));
     }
@@ -551,7 +570,8 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     // stream it runs before the next pack kernel starts.
     const bool scan_main = pipelined && c->scan_on_main;
     hipStream_t ss = scan_main ? c->stream : tail;
-    if (scan_main && split) HIP_TRY(hipStreamWaitEvent(c->stream, c->packed2[c->flip], 0));   // the index reads both parts' meta words
+    if (scan_main && split)   // the index reads every part's meta words
+        for (int p = 0; p + 1 < c->parts; p++) HIP_TRY(hipStreamWaitEvent(c->stream, c->packed2[p][c->flip], 0));
     if (pipelined && !scan_main) {
         HIP_TRY(hipEventRecord(ls.packed, c->stream));
         HIP_TRY(hipStreamWaitEvent(tail, ls.packed, 0));
@@ -693,8 +713,8 @@ void mi355_destroy(mi355_core *c) {
             if (ls.expanded) (void)hipEventDestroy(ls.expanded);
         }
         if (c->side) (void)hipStreamDestroy(c->side);
-        if (c->main2) { (void)hipStreamSynchronize(c->main2); (void)hipStreamDestroy(c->main2); }
-        for (auto &e : c->packed2) if (e) (void)hipEventDestroy(e);
+        for (auto &m : c->main2) if (m) { (void)hipStreamSynchronize(m); (void)hipStreamDestroy(m); }
+        for (auto &pe : c->packed2) for (auto &e : pe) if (e) (void)hipEventDestroy(e);
     }
     void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->codes, c->meta, c->groff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
                     c->lut, c->glyphs, c->kxk, c->gray1, c->red_bounds, c->f_wgsum, c->f_sync, c->f_spill, c->f_ovf, c->f_ready, c->c_desc, c->c_status};
