@@ -764,7 +764,7 @@ def regimes(args, dev, B=32):
     return out
 
 
-def filter_configs(args, dev, B=96, reps=10):
+def filter_configs(args, dev, B=192, reps=10):
     """BASELINE configs 3 and 4 end to end on a resident batch (what the server does with a frame when the
     visualiser / noise filter is on, kernels.cu:457-520): the visualiser's frame AND the packed diff stream.
       config3: weighted grayscale + histogram + two-max + binarize (one gray byte per pixel kept between the two

@@ -42,6 +42,9 @@ namespace mi355 {
 #define MI355_ABLATE 0
 #endif
 
+#ifndef MI355_K1STNT   // timing builds: 1 = code stores, 2 = record stores, 4 = meta stores of the pack kernel non-temporal
+#define MI355_K1STNT 0
+#endif
 #ifndef MI355_K1_PREFETCH
 #define MI355_K1_PREFETCH 4
 #endif
@@ -157,7 +160,7 @@ __device__ __forceinline__ uint32_t emit_step(const uint32_t (&dm)[4], uint32_t 
                        // lane's record is record `lane`, and its map is the record's non-zero bytes (|df| > T >= 0 is never 0)
 #if MI355_ABLATE == 0
         const u32x4 v = {dm[0], dm[1], dm[2], dm[3]};
-        __builtin_amdgcn_raw_buffer_store_b128(v, lg.recs, pm + rankM * 16u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, lg.recs, pm + rankM * 16u, 0, (MI355_K1STNT & 2) ? 2 : 0);
 #endif
         lp.ptrM += 64u * 16u;
         lp.roomM -= 64u;
@@ -170,9 +173,9 @@ __device__ __forceinline__ uint32_t emit_step(const uint32_t (&dm)[4], uint32_t 
     const uint32_t one = __builtin_amdgcn_sad_u8((dm[0] | dm[1]) | (dm[2] | dm[3]), 0u, 0u);
     const uint32_t code = m16 | ((multi ? rankM : one) << 16) | lane24;
 #if MI355_ABLATE == 0
-    __builtin_amdgcn_raw_buffer_store_b32(code, lg.codes, cand ? pc + rankC * 4u : kOOB, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(code, lg.codes, cand ? pc + rankC * 4u : kOOB, 0, (MI355_K1STNT & 1) ? 2 : 0);
     const u32x4 v = {dm[0], dm[1], dm[2], dm[3]};
-    __builtin_amdgcn_raw_buffer_store_b128(v, lg.recs, multi ? pm + rankM * 16u : kOOB, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, lg.recs, multi ? pm + rankM * 16u : kOOB, 0, (MI355_K1STNT & 2) ? 2 : 0);
 #else
     asm volatile("" ::"v"(dm[0]), "v"(dm[1]), "v"(dm[2]), "v"(dm[3]), "v"(rankC), "v"(rankM), "v"(code));
 #endif
@@ -268,7 +271,7 @@ __device__ __forceinline__ void pack_group(const PackArgs &a, const Group<PAIR, 
 #if MI355_ABLATE != 2 && MI355_ABLATE != 3
     const uint32_t moff = (__umul24((uint32_t)t0 + (uint32_t)lane, a.ntiles) + tile) * 16u;
     const u32x4 mv = {meta.x, meta.y, meta.z, meta.w};
-    __builtin_amdgcn_raw_buffer_store_b128(mv, lg.meta, (lane < kPrefetch && t0 + lane < a.nframes) ? moff : kOOB, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(mv, lg.meta, (lane < kPrefetch && t0 + lane < a.nframes) ? moff : kOOB, 0, (MI355_K1STNT & 4) ? 2 : 0);
 #endif
 }
 
@@ -584,9 +587,38 @@ __device__ __forceinline__ void lds_handoff() {
 // to a lane: one ds_read_b128, one 16-byte store of the four indices and one dword of the four differences (gfx950
 // global stores need no alignment: the index section is dword aligned in the packed form and byte aligned on the
 // wire, the differences start at any byte).
-struct __attribute__((packed, aligned(4))) U32x4A4 { uint32_t x, y, z, w; };
-struct __attribute__((packed, aligned(1))) U32x4A1 { uint32_t x, y, z, w; };
-struct __attribute__((packed, aligned(1))) U32A1 { uint32_t x; };
+// The packed stream is written once and not read again by this library's path: its stores are NON-TEMPORAL (round 4), so
+// that they do not push the logs -- written by the pack kernel, read back here one batch later -- out of the caches.
+// Measured (profiles/r04an, r04ao): the batch 4-5 % faster on the slower boards of the pool (0.502 -> 0.479 ms) and
+// sequentially (0.537 -> 0.514), unchanged on the fastest; MI355_XNT=0 builds the plain stores.  (Round 1 measured the
+// opposite for its 4-byte + 1-byte scattered stores, r01d: a non-temporal store wants whole 16-byte pieces.)
+#ifndef MI355_XNT
+#define MI355_XNT 1
+#endif
+#ifndef MI355_XLOGNT   // timing builds: 1 = code loads, 2 = record loads, 4 = meta loads of the expander non-temporal
+#define MI355_XLOGNT 0
+#endif
+typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint32_t u32a1 __attribute__((aligned(1)));
+template <bool BYTE_ALIGNED>
+__device__ __forceinline__ void store_out4(uint8_t *p, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+    const u32x4 v = {x, y, z, w};
+#if MI355_XNT
+    if (BYTE_ALIGNED) __builtin_nontemporal_store(v, reinterpret_cast<u32x4a1 *>(p));
+    else __builtin_nontemporal_store(v, reinterpret_cast<u32x4a4 *>(p));
+#else
+    if (BYTE_ALIGNED) *reinterpret_cast<u32x4a1 *>(p) = v;
+    else *reinterpret_cast<u32x4a4 *>(p) = v;
+#endif
+}
+__device__ __forceinline__ void store_out1(uint8_t *p, uint32_t v) {   // any byte address
+#if MI355_XNT
+    __builtin_nontemporal_store(v, reinterpret_cast<u32a1 *>(p));
+#else
+    *reinterpret_cast<u32a1 *>(p) = v;
+#endif
+}
 
 template <bool WIRE>
 __device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint32_t *stage, uint32_t first, uint32_t count,
@@ -608,11 +640,10 @@ __device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint32_
     for (uint32_t k = lane; k < n4; k += 64u) {
         const uint4 q = *reinterpret_cast<const uint4 *>(stage + 4 * k);
         const uint32_t x0 = xs0 + (q.x >> 8), x1 = xs0 + (q.y >> 8), x2 = xs0 + (q.z >> 8), x3 = xs0 + (q.w >> 8);
-        if (WIRE) *reinterpret_cast<U32x4A1 *>(xsp + 16 * (size_t)k) = U32x4A1{x0, x1, x2, x3};
-        else *reinterpret_cast<U32x4A4 *>(xsp + 16 * (size_t)k) = U32x4A4{x0, x1, x2, x3};
+        store_out4<WIRE>(xsp + 16 * (size_t)k, x0, x1, x2, x3);
         // the low bytes of the four entries: v_perm picks byte 0 of two dwords at a time
         const uint32_t lo = __builtin_amdgcn_perm(q.y, q.x, 0x0c0c0400u), hi = __builtin_amdgcn_perm(q.w, q.z, 0x04000c0cu);
-        *reinterpret_cast<U32A1 *>(dfp + 4 * (size_t)k) = U32A1{lo | hi};
+        store_out1(dfp + 4 * (size_t)k, lo | hi);
     }
     const uint32_t tail = 4u * n4 + lane;   // the up to three entries left
     if (tail < n) {
@@ -738,7 +769,7 @@ __device__ __forceinline__ void expand_pairs(const ExpandArgs &a, uint32_t mx, u
         const uint32_t nc_a = (uint32_t)__builtin_amdgcn_readlane((int)mz, 2 * r) >> 16, nc_b = (uint32_t)__builtin_amdgcn_readlane((int)mz, 2 * r + 1) >> 16;
         const uint32_t pc_a = (uint32_t)__builtin_amdgcn_readlane((int)mx, 2 * r), pc_b = (uint32_t)__builtin_amdgcn_readlane((int)mx, 2 * r + 1);
         const uint32_t off = lane >= nc_a ? lane4 + (pc_b - 4u * nc_a) : lane4 + pc_a;
-        code[r] = __builtin_amdgcn_raw_buffer_load_b32(codes, lane < nc_a + nc_b ? off : kOOB, 0, 0);   // a lane without a candidate reads 0
+        code[r] = __builtin_amdgcn_raw_buffer_load_b32(codes, lane < nc_a + nc_b ? off : kOOB, 0, (MI355_XLOGNT & 1) ? 2 : 0);   // a lane without a candidate reads 0
     }
 #if MI355_XFABLATE == 2
     { uint32_t acc = 0;
@@ -788,7 +819,7 @@ __device__ __forceinline__ void expand_pairs(const ExpandArgs &a, uint32_t mx, u
     lds_handoff();
     // the first 64 queued lanes' records (an item rarely queues more)
     const uint2 w0 = list[lane];
-    const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(recs, lane < tail ? (w0.x << 4) : kOOB, 0, 0);
+    const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(recs, lane < tail ? (w0.x << 4) : kOOB, 0, (MI355_XLOGNT & 2) ? 2 : 0);
     __builtin_amdgcn_sched_barrier(0);
     XSTAMP(5);                                    // queued, records requested
 #pragma unroll
@@ -813,7 +844,7 @@ __device__ __forceinline__ void expand_pairs(const ExpandArgs &a, uint32_t mx, u
     for (uint32_t head = 64u; head < tail; head += 64u) {   // the rest, 64 at a time
         const bool on = head + lane < tail;
         const uint2 w = list[min(head + lane, kFList - 1u)];
-        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(recs, on ? (w.x << 4) : kOOB, 0, 0);
+        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(recs, on ? (w.x << 4) : kOOB, 0, (MI355_XLOGNT & 2) ? 2 : 0);
         walk_records(on ? (w.y & 0xffffu) : 0u, (w.y >> 16) & 0x3ffu, ((w.x >> 28) << 10) | ((w.y >> 26) << 4),
                      make_uint4(q.x, q.y, q.z, q.w), stage, lane);
     }
@@ -835,7 +866,7 @@ __device__ __forceinline__ void expand_tiles(const ExpandArgs &a, const uint4 *t
     auto load_code = [&](uint32_t i) {
         const uint4 ti = tinfo[i & (kWTiles - 1u)];
         const bool dense = MI355_RECORD_ONLY && (ti.w >> 16) == 64u;
-        return __builtin_amdgcn_raw_buffer_load_b32(codes, (i < kWTiles && !dense && lane < (ti.w & 0xffffu)) ? ti.x + 4u * lane : kOOB, 0, 0);
+        return __builtin_amdgcn_raw_buffer_load_b32(codes, (i < kWTiles && !dense && lane < (ti.w & 0xffffu)) ? ti.x + 4u * lane : kOOB, 0, (MI355_XLOGNT & 1) ? 2 : 0);
     };
     auto load_rec = [&](uint32_t i, uint32_t c) {
         const uint4 ti = tinfo[i & (kWTiles - 1u)];
@@ -843,7 +874,7 @@ __device__ __forceinline__ void expand_tiles(const ExpandArgs &a, const uint4 *t
         const bool dense = MI355_RECORD_ONLY ? (ti.w >> 16) == 64u : ti.z == kTileBytes;
         // a dense tile: record `lane`; otherwise the record of a lane with two or more flagged bytes
         const uint32_t off = dense ? ti.y + 16u * lane : ((m16 & (m16 - 1u)) ? ti.y + 16u * ((c >> 16) & 0xffu) : kOOB);
-        return __builtin_amdgcn_raw_buffer_load_b128(recs, i < kWTiles ? off : kOOB, 0, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(recs, i < kWTiles ? off : kOOB, 0, (MI355_XLOGNT & 2) ? 2 : 0);
     };
     uint32_t carry = 0, flushed = 0;   // entries of the item expanded so far / already stored (wave-uniform)
     uint32_t c0 = load_code(0), c1 = load_code(1);
@@ -872,8 +903,8 @@ __device__ __forceinline__ void expand_tiles(const ExpandArgs &a, const uint4 *t
                 const uint32_t x = xs0 + (i << 10) + 4u * lane;
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++)
-                    *reinterpret_cast<U32x4A1 *>(xsp + 1024 * k + 16 * lane) = U32x4A1{x + 256 * k, x + 256 * k + 1, x + 256 * k + 2, x + 256 * k + 3};
-                *reinterpret_cast<U32x4A1 *>(dfp + 16 * lane) = U32x4A1{r0.x, r0.y, r0.z, r0.w};
+                    store_out4<true>(xsp + 1024 * k + 16 * lane, x + 256 * k, x + 256 * k + 1, x + 256 * k + 2, x + 256 * k + 3);
+                store_out4<true>(dfp + 16 * lane, r0.x, r0.y, r0.z, r0.w);
                 flushed = carry + kTileBytes;
             } else {
                 const uint4 r = make_uint4(r0.x, r0.y, r0.z, r0.w);
@@ -925,7 +956,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // lanes << 16}; the other lanes (and tiles beyond the frame) read nothing and get zeros
     const uint32_t tile = sub * kWTiles + lane;
     const __amdgpu_buffer_rsrc_t metas = make_rsrc(a.meta + (size_t)t * a.ntiles, a.ntiles * 16u);
-    const u32x4 mq = __builtin_amdgcn_raw_buffer_load_b128(metas, lane < kWTiles ? tile * 16u : kOOB, 0, 0);
+    const u32x4 mq = __builtin_amdgcn_raw_buffer_load_b128(metas, lane < kWTiles ? tile * 16u : kOOB, 0, (MI355_XLOGNT & 4) ? 2 : 0);
     const uint32_t off_t = a.offsets[t];                                        // entries of the frames before t
     const uint32_t roff = a.roff[(size_t)t * ngroups * 4u + sub];               // entries of frame t before the item's tiles
     const uint32_t n_t = WIRE ? a.offsets[t + 1] - off_t : 0u;                  // entries of frame t

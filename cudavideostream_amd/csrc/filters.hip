@@ -35,6 +35,27 @@ __device__ __forceinline__ Px16 load_px16(const uint8_t *p, int nbytes) {
     return r;
 }
 
+// The same 48 bytes with non-temporal loads (MI355_FILT_NT_LOAD=1, a timing build): measured 10 % SLOWER (gray 2.07 -> 2.37 us
+// per frame, profiles/r04au): a 128-byte line is touched by three of these loads, 16 bytes per lane at a 48-byte
+// stride, and a non-temporal line does not wait in the cache for the other two.
+#ifndef MI355_FILT_NT_LOAD
+#define MI355_FILT_NT_LOAD 0
+#endif
+__device__ __forceinline__ Px16 load_px16_once(const uint8_t *p) {
+#if MI355_FILT_NT_LOAD
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const v4 *q = reinterpret_cast<const v4 *>(p);
+    const v4 a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1), c = __builtin_nontemporal_load(q + 2);
+    Px16 r;
+    r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
+    r.w[4] = b.x; r.w[5] = b.y; r.w[6] = b.z; r.w[7] = b.w;
+    r.w[8] = c.x; r.w[9] = c.y; r.w[10] = c.z; r.w[11] = c.w;
+    return r;
+#else
+    return load_px16<true>(p, 48);
+#endif
+}
+
 template <bool FAST>
 __device__ __forceinline__ void store_px16(uint8_t *p, const Px16 &r, int nbytes) {
     if (FAST) {
@@ -58,6 +79,13 @@ __device__ __forceinline__ void store_px16(uint8_t *p, const Px16 &r, int nbytes
 #ifndef MI355_FILT_LDS_STORE
 #define MI355_FILT_LDS_STORE 1
 #endif
+// ... and they are NON-TEMPORAL stores (round 4): a visualiser frame is written once and read by nobody on this path; kept
+// out of the caches it leaves them to the frames and logs of the diff that follows (fused gray+binarize 2.90 -> 2.74 us per
+// 1080p frame, config 3's chain 4.9 -> 4.75-4.85; the noise filter's output, which the diff reads next, gains nothing:
+// profiles/r04at_filters_nt_stores.log).
+#ifndef MI355_FILT_NT_STORE
+#define MI355_FILT_NT_STORE 1
+#endif
 __device__ __forceinline__ void store_px16_wave(uint8_t *wave_base, const Px16 &r, uint4 *lds /* 192 per wave */) {
     const uint32_t lane = threadIdx.x & 63u;
     lds[lane * 3u + 0u] = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
@@ -67,7 +95,15 @@ __device__ __forceinline__ void store_px16_wave(uint8_t *wave_base, const Px16 &
     __builtin_amdgcn_wave_barrier();
     uint4 *q = reinterpret_cast<uint4 *>(wave_base);
 #pragma unroll
-    for (uint32_t j = 0; j < 3; j++) q[j * 64u + lane] = lds[j * 64u + lane];
+    for (uint32_t j = 0; j < 3; j++) {
+#if MI355_FILT_NT_STORE
+        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+        const uint4 t = lds[j * 64u + lane];
+        __builtin_nontemporal_store(v4{t.x, t.y, t.z, t.w}, reinterpret_cast<v4 *>(q + j * 64u + lane));
+#else
+        q[j * 64u + lane] = lds[j * 64u + lane];
+#endif
+    }
 }
 
 // The load side of the same regrouping: three wave-contiguous 1 KiB loads, the lanes' 48-byte pieces read back from LDS.
@@ -228,7 +264,7 @@ __global__ __launch_bounds__(256) void k_gray(const uint8_t *in, uint8_t *out, u
     const uint32_t rem = npix - lane_px;
     const size_t off = (size_t)lane_px * 3;
     if (FAST && rem >= 16) {
-        const Px16 p = load_px16_full(in, off);
+        const Px16 p = load_px16_once(in + off);
         Px16 q;
 #pragma unroll
         for (int i = 0; i < 12; i++) q.w[i] = 0;
@@ -296,7 +332,8 @@ __global__ __launch_bounds__(256) void k_histogram(const uint8_t *img, uint32_t 
     if (whole) {
         Px16 p[kHistBlocks];
 #pragma unroll
-        for (int it = 0; it < kHistBlocks; it++) p[it] = load_px16<true>(img + (size_t)(px0 + it * 4096u) * 3, 48);
+        for (int it = 0; it < kHistBlocks; it++)
+            p[it] = MODE != 0 ? load_px16_once(img + (size_t)(px0 + it * 4096u) * 3) : load_px16<true>(img + (size_t)(px0 + it * 4096u) * 3, 48);
 #pragma unroll
         for (int it = 0; it < kHistBlocks; it++) {
             uint32_t gw[4] = {0, 0, 0, 0};
@@ -745,7 +782,13 @@ __global__ __launch_bounds__(256) void k_red_stream_clear(uint8_t *out, size_t s
 #pragma unroll
     for (uint32_t j = 0; j < 3; j++) {
         const uint32_t o = (j * 64u + lane) * 16u;
+#if MI355_FILT_NT_STORE
+        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+        const uint4 t = sl[j * 64u + lane];
+        if (o + 16u <= len) __builtin_nontemporal_store(v4{t.x, t.y, t.z, t.w}, reinterpret_cast<v4 *>(img + o));
+#else
         if (o + 16u <= len) *reinterpret_cast<uint4 *>(img + o) = sl[j * 64u + lane];
+#endif
         else for (uint32_t k = o; k < len; k++) img[k] = bytes[k];
     }
 }
@@ -822,6 +865,9 @@ __device__ __forceinline__ float byte_f(uint32_t dw, int b) {  // b is a compile
 // byte<->float conversion costs a wave as much as two multiplies, and packed fp32 instructions issue at
 // half the rate of plain ones, i.e. no faster per element): ~13 instructions per output byte (SYM), ~15
 // (general), against 18 for the LDS-tiled row kernel it replaced (4.24 -> 3.53 us per 1080p frame).
+#ifndef MI355_CONV_NT_STORE
+#define MI355_CONV_NT_STORE 0
+#endif
 #ifndef MI355_CONV_STRIP
 #define MI355_CONV_STRIP 30
 #endif
@@ -920,7 +966,12 @@ void k_conv3x3_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, const
             for (int d = 0; d < NW; d++)
                 o[d] = f32x4_to_u8x4(B[2 * d].x, B[2 * d].y, B[2 * d + 1].x, B[2 * d + 1].y);   // :131-133
             uint8_t *dst = out + (size_t)(r - 1) * rowbytes + xb;
+#if MI355_CONV_NT_STORE
+            typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+            if (NW == 4) __builtin_nontemporal_store(v4{o[0], o[1], o[NW - 2], o[NW - 1]}, reinterpret_cast<v4 *>(dst));
+#else
             if (NW == 4) *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[NW - 2], o[NW - 1]);
+#endif
             else *reinterpret_cast<uint2 *>(dst) = make_uint2(o[0], o[NW - 1]);
         }
         __builtin_amdgcn_sched_barrier(0);   // one row at a time: fewer products live at once
