@@ -534,6 +534,21 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     // the vector path of the pack kernel: 16-byte aligned operands, and a group of four frames within reach of one
     // buffer descriptor's 32-bit offsets (diff_pack.hip, Group::load_desc)
     const bool aligned = (((uintptr_t)d_cur | (uintptr_t)d_prev | stride) & 15u) == 0 && 3 * (uint64_t)stride + c->n < (1ull << 32);
+    // Pair mode: do the two operands share a frame (or part of one), i.e. does prev + j * stride come within a frame of
+    // cur + i * stride for some i, j < T?  Pairs of consecutive frames do (cur of one pair is prev of the next: the second
+    // read hits in the caches); the pairs of a round-robin shard do not, and are read with non-temporal loads like the
+    // frames of a stream (diff_pack.hip, Group::load_desc).
+    bool pair_once = false;
+    if (pair) {
+        const int64_t d = (int64_t)((intptr_t)d_prev - (intptr_t)d_cur), st = (int64_t)stride, T = nframes;
+        bool shared = false;
+        const int64_t k0 = d / st;
+        for (int64_t k = k0 - 1; k <= k0 + 1; k++)
+            if (k > -T && k < T && (d - k * st < 0 ? k * st - d : d - k * st) < (int64_t)c->n) shared = true;
+        pair_once = !shared;
+        static const char *force = getenv("MI355_PAIR_ONCE");   // "0" / "1": A/B runs
+        if (force) pair_once = force[0] == '1';
+    }
     const bool split = pipelined && c->split_pct && c->main2[0] && c->ntiles >= 64;
     if (split) {
         // first part on the core's stream, the others on streams of their own (which also have to see the log set free);
@@ -554,7 +569,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
             ap.tile_end = end;
             hipStream_t sp = p == 0 ? c->stream : c->main2[p - 1];
             if (p > 0 && ls.in_use) HIP_TRY(hipStreamWaitEvent(sp, ls.expanded, 0));
-            HIP_TRY(launch_diff_pack(ap, pair, aligned, blocks, sp));
+            HIP_TRY(launch_diff_pack(ap, pair, aligned, pair_once, blocks, sp));
             if (p > 0) {
                 HIP_TRY(hipEventRecord(c->packed2[p - 1][c->flip], sp));
                 HIP_TRY(hipStreamWaitEvent(tail, c->packed2[p - 1][c->flip], 0));
@@ -562,7 +577,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
             begin = end;
         }
     } else {
-        HIP_TRY(launch_diff_pack(a, pair, aligned, pipelined ? c->k1_blocks : 0u, c->stream));
+        HIP_TRY(launch_diff_pack(a, pair, aligned, pair_once, pipelined ? c->k1_blocks : 0u, c->stream));
     }
     if (tev) HIP_TRY(hipEventRecord(tev[1], c->stream));
     // The index kernel is short (12 us alone) and gates the expansion: behind the next batch's pack kernel on the side

@@ -200,13 +200,18 @@ struct Group {
     // all (round 3: 8 scalar instructions to clamp the frame pointer to the last frame + a 64-bit vector add per load;
     // scalar instructions are not free on this chip: ~2.6 cycles of the SIMD's issue time each, profiles/r04n), and
     // frames beyond the batch are out of the descriptor's range: they return zeros and read nothing.
+    // ONCE: every frame is read once by this batch -- the frames of a stream, or pairs whose operands share no frame
+    // (round-robin shards: pairs (f - 1, f) of every 8th f): non-temporal loads, +7 % for such pairs (0.355 -> 0.332 ms per
+    // 128 pairs of 1080p, 4K 0.60 -> 0.63 of the roofline); pairs of CONSECUTIVE frames, where cur of one pair is prev of
+    // the next, keep the plain policy (the second read hits): non-temporal loads cost them 6 % (profiles/r04av).
+    template <bool ONCE>
     __device__ __forceinline__ void load_desc(__amdgpu_buffer_rsrc_t cur, __amdgpu_buffer_rsrc_t prev, const uint32_t (&voff)[kPrefetch]) {
 #pragma unroll
         for (int d = 0; d < kPrefetch; d++) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(cur, voff[d], 0, (!PAIR && MI355_NT_LOADS) ? 2 : 0);   // stream frames: read once (nt)
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(cur, voff[d], 0, (ONCE && MI355_NT_LOADS) ? 2 : 0);
             c[d] = make_uint4(v.x, v.y, v.z, v.w);
             if (PAIR) {
-                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(prev, voff[d], 0, 0);
+                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(prev, voff[d], 0, (ONCE && MI355_NT_LOADS) ? 2 : 0);
                 p[d] = make_uint4(w.x, w.y, w.z, w.w);
             }
         }
@@ -275,7 +280,7 @@ __device__ __forceinline__ void pack_group(const PackArgs &a, const Group<PAIR, 
 #endif
 }
 
-template <bool PAIR, bool FAST, bool HIGH>
+template <bool PAIR, bool FAST, bool HIGH, bool ONCE>
 __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint32_t byte_off,
                                           int valid, int lane) {
     const int T = a.nframes;
@@ -312,15 +317,15 @@ __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint
             const uint32_t bytes = left <= 0 ? 0u : (left > 0xffffffffll ? 0xffffffffu : (uint32_t)left);
             return make_rsrc(base, bytes);
         };
-        ga.load_desc(desc(cb), desc(pb), voff);
+        ga.template load_desc<ONCE>(desc(cb), desc(pb), voff);
         for (int t0 = 0;;) {
             cb += gstep; if (PAIR) pb += gstep; left -= (int64_t)gstep;
-            gb.load_desc(desc(cb), desc(pb), voff);
+            gb.template load_desc<ONCE>(desc(cb), desc(pb), voff);
             pack_group<PAIR, FAST, HIGH>(a, ga, t0, st, lp, tile, tc, lane, lg);
             t0 += kPrefetch;
             if (t0 >= T) break;
             cb += gstep; if (PAIR) pb += gstep; left -= (int64_t)gstep;
-            ga.load_desc(desc(cb), desc(pb), voff);
+            ga.template load_desc<ONCE>(desc(cb), desc(pb), voff);
             pack_group<PAIR, FAST, HIGH>(a, gb, t0, st, lp, tile, tc, lane, lg);
             t0 += kPrefetch;
             if (t0 >= T) break;
@@ -351,7 +356,7 @@ __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint
     }
 }
 
-template <bool PAIR, bool ALIGNED, bool HIGH>
+template <bool PAIR, bool ALIGNED, bool HIGH, bool ONCE = !PAIR>
 __global__ __launch_bounds__(256) void k_diff_pack(const PackArgs a) {
 #if MI355_K1PRIO
     __builtin_amdgcn_s_setprio(MI355_K1PRIO);
@@ -375,15 +380,15 @@ __global__ __launch_bounds__(256) void k_diff_pack(const PackArgs a) {
         const uint32_t byte_off = tile_off + (uint32_t)lane * 16u;
         // wave-uniform choice: every lane of a full, aligned tile takes the vector path
         if (ALIGNED && tile_off + kTileBytes <= a.n) {
-            pack_tile<PAIR, true, HIGH>(a, tile, byte_off, 16, lane);
+            pack_tile<PAIR, true, HIGH, ONCE>(a, tile, byte_off, 16, lane);
         } else {
             const int valid = byte_off < a.n ? (int)min(16u, a.n - byte_off) : 0;
-            pack_tile<PAIR, false, HIGH>(a, tile, byte_off, valid, lane);
+            pack_tile<PAIR, false, HIGH, ONCE>(a, tile, byte_off, valid, lane);
         }
     }
 }
 
-hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, uint32_t max_blocks, hipStream_t s) {
+hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, bool pair_once, uint32_t max_blocks, hipStream_t s) {
     const dim3 block(64 * kWavesPerBlock);
     uint32_t blocks = (a.tile_end - a.tile_begin + kWavesPerBlock - 1) / kWavesPerBlock;
     if (max_blocks && max_blocks < blocks) blocks = max_blocks;
@@ -398,7 +403,10 @@ hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, uint32_t
         else hipLaunchKernelGGL((k_diff_pack<P, A, false>), grid, block, 0, s, a);                     \
     } while (0)
     if (pair) {
-        if (aligned) MI355_LAUNCH_PACK(true, true);
+        if (aligned && pair_once) {   // operands that share no frame (core.hip, run_batch)
+            if (high) hipLaunchKernelGGL((k_diff_pack<true, true, true, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((k_diff_pack<true, true, false, true>), grid, block, 0, s, a);
+        } else if (aligned) MI355_LAUNCH_PACK(true, true);
         else MI355_LAUNCH_PACK(true, false);
     } else {
         if (aligned) MI355_LAUNCH_PACK(false, true);

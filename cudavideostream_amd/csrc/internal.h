@@ -111,7 +111,8 @@ hipStream_t core_stream(::mi355_core *c);   // the stream the core currently enq
 int core_device(const ::mi355_core *c);
 
 // diff_pack.hip
-hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, uint32_t max_blocks /* 0: one tile per wave */, hipStream_t s);
+hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, bool pair_once /* pair mode: no frame is an operand twice */,
+                            uint32_t max_blocks /* 0: one tile per wave */, hipStream_t s);
 uint32_t expand_groups(uint32_t ntiles);
 hipError_t launch_scan(const uint4 *meta, uint32_t *roff, uint32_t *totals, uint32_t ntiles,
                        int nframes, uint32_t *offsets, uint32_t *ticket /* zero between launches */,

@@ -134,6 +134,24 @@ def test_pair_mode_refrand(po):
         assert np.array_equal(core.get_state(), marker)
 
 
+def test_pairs_of_consecutive_frames_and_of_disjoint_frames(po):
+    """Pair mode picks its load policy from the operands (core.hip, run_batch): views of ONE buffer as pairs of consecutive
+    frames (cur of a pair is prev of the next: the plain loads) and as pairs (0,1), (2,3), ... with a stride of two frames
+    (a round-robin shard: no frame twice, the non-temporal loads), 16-byte aligned and not; both against the oracle."""
+    for w, h, T in ((320, 180, 6), (97, 13, 5)):
+        n = 3 * w * h
+        _, frames = synth.webcam_stream(2 * T, w, h, seed=77)
+        frames = np.ascontiguousarray(frames)
+        buf = to_dev(frames)
+        with CUDACore(w, h, max_batch=T) as core:
+            off, xs, df, _ = run_stream(core, buf[1:T + 1], pair_prev=buf[0:T])
+            eo, exs, edf = oracle_pairs(po, frames[1:T + 1], frames[0:T])
+            assert np.array_equal(off, eo) and np.array_equal(xs, exs) and np.array_equal(df, edf)
+            off, xs, df, _ = run_stream(core, buf[1::2], pair_prev=buf[0::2], stride=2 * n)
+            eo, exs, edf = oracle_pairs(po, frames[1::2], frames[0::2])
+            assert np.array_equal(off, eo) and np.array_equal(xs, exs) and np.array_equal(df, edf)
+
+
 def test_capacity_truncation_keeps_offsets_exact(po):
     base, frames = synth.webcam_stream(4, 64, 48, seed=8)
     eo, exs, edf, _ = po.diff_stream(frames, base)

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64) void k_corun_mem(const uint4 *buf, size_t nvec,
 int main(int argc, char **argv) {
     int W = 1920, H = 1080, B = 256, K = 20, WU = 3, checksum_t = -2, ncores = 1;
     uint32_t seed = 21;
-    bool pairs = false, filters = false, digest = false;
+    bool pairs = false, filters = false, digest = false, apart = false;
     const char *corun = nullptr; int corun_blocks = 2048;
     const char *regime = nullptr;   // --regime s0|flip|static: pairs of the dense / static regimes (tools/bench_regimes.py's inputs)
     for (int i = 1; i < argc; i++) {
@@ -100,6 +100,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--seed")) { int s = 21; next(s); seed = (uint32_t)s; }
         else if (!strcmp(argv[i], "--checksum")) next(checksum_t);
         else if (!strcmp(argv[i], "--pairs")) pairs = true;
+        else if (!strcmp(argv[i], "--apart")) { pairs = true; apart = true; }   // pairs (0,1), (2,3), ...: no frame is an operand twice (round-robin sharding)
         else if (!strcmp(argv[i], "--cores")) next(ncores);
         else if (!strcmp(argv[i], "--filters")) filters = true;
         else if (!strcmp(argv[i], "--digest")) digest = true;
@@ -215,11 +216,12 @@ int main(int argc, char **argv) {
     MI_OK(mi355_create(&cfg, &core));
 
     uint8_t *d_frames = nullptr, *d_base = nullptr;
-    HIP_OK(hipMalloc((void **)&d_frames, n * (size_t)(B + 1)));
+    const int nfr = apart ? 2 * B : B + 1;
+    HIP_OK(hipMalloc((void **)&d_frames, n * (size_t)nfr));
     HIP_OK(hipMalloc((void **)&d_base, n));
     const dim3 g((unsigned)((n + 255) / 256)), b(256);
     hipLaunchKernelGGL(k_webcam_frame, g, b, 0, 0, d_base, -1, W, H, seed);
-    for (int t = 0; t <= B; t++)
+    for (int t = 0; t < nfr; t++)
         hipLaunchKernelGGL(k_webcam_frame, g, b, 0, 0, d_frames + (size_t)t * n, t, W, H, seed);
     HIP_OK(hipDeviceSynchronize());
     std::vector<uint8_t> h_base(n);
@@ -246,7 +248,7 @@ int main(int argc, char **argv) {
     HIP_OK(hipMalloc((void **)&d_df, cap));
 
     auto step = [&]() {
-        if (pairs) MI_OK(mi355_diff_pairs_batch(core, d_cur, d_prev, n, B, d_off, d_xs, d_df, cap));
+        if (pairs) MI_OK(mi355_diff_pairs_batch(core, d_cur, d_prev, apart ? 2 * n : n, B, d_off, d_xs, d_df, cap));
         else MI_OK(mi355_diff_stream_batch(core, d_frames, n, B, d_off, d_xs, d_df, cap));
     };
     for (int i = 0; i < WU; i++) step();
