@@ -20,6 +20,10 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t
 # `python3 bench.py` any more: that pass crashed in every round (profiles/r02{g,h,i}_pmc_under_python.log) and its
 # cause is known -- see profiles/README.md, "counter passes under PyTorch": the process then holds two HSA/HIP
 # runtimes (PyTorch's bundled ROCm 7.0 copies and the profiler's /opt/rocm 7.2 ones).
+# MI355_PIPELINE=0: one launch of every kernel per batch (a pipelined batch is packed by TWO k_diff_pack launches, half
+# the tiles each -- csrc/core.hip, MI355_SPLIT -- and "bytes per launch" would be half a batch); the bytes a kernel moves
+# do not depend on what runs beside it.
+export MI355_PIPELINE=0
 DB="tools/diffbench --steps $STEPS --warmup 2"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $DB > $OUT/fetch.log 2>&1 || echo "fetch failed"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $DB > $OUT/write.log 2>&1 || echo "write failed"
