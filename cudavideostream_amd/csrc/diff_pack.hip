@@ -45,6 +45,9 @@ namespace mi355 {
 #ifndef MI355_K1STNT   // timing builds: 1 = code stores, 2 = record stores, 4 = meta stores of the pack kernel non-temporal
 #define MI355_K1STNT 0
 #endif
+#ifndef MI355_K1_LDAUX   // cache policy bits of the once-read frame loads: 1 = sc0, 2 = nt, 16 = sc1 (timing builds try the others)
+#define MI355_K1_LDAUX 2
+#endif
 #ifndef MI355_K1_PREFETCH
 #define MI355_K1_PREFETCH 4
 #endif
@@ -208,7 +211,7 @@ struct Group {
     __device__ __forceinline__ void load_desc(__amdgpu_buffer_rsrc_t cur, __amdgpu_buffer_rsrc_t prev, const uint32_t (&voff)[kPrefetch]) {
 #pragma unroll
         for (int d = 0; d < kPrefetch; d++) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(cur, voff[d], 0, (ONCE && MI355_NT_LOADS) ? 2 : 0);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(cur, voff[d], 0, (ONCE && MI355_NT_LOADS) ? MI355_K1_LDAUX : 0);
             c[d] = make_uint4(v.x, v.y, v.z, v.w);
             if (PAIR) {
                 const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(prev, voff[d], 0, (ONCE && MI355_NT_LOADS) ? 2 : 0);

@@ -433,6 +433,40 @@ def test_back_to_back_batches_without_synchronisation(po):
         at += tot
 
 
+def test_back_to_back_pair_batches_without_synchronisation(po):
+    """Pair mode on the core's own stream: five batches queued back to back (two pack launches per batch on two streams, the
+    expansion beside the next batch's pack kernels), alternately pairs of consecutive frames (plain loads) and pairs that
+    share no frame (non-temporal loads); one synchronisation at the end; every batch against the oracle, state untouched."""
+    w, h, T, K = 320, 180, 5, 5
+    n = 3 * w * h
+    _, frames = synth.webcam_stream(2 * T * K, w, h, seed=91)
+    frames = np.ascontiguousarray(frames)
+    d_fr = to_dev(frames)
+    marker = synth.refrand_frame(n, 5)
+    outs = [(torch.zeros(T + 1, dtype=torch.int32, device=DEV), torch.full((T * n,), -7, dtype=torch.int32, device=DEV),
+             torch.zeros(T * n, dtype=torch.uint8, device=DEV)) for _ in range(K)]
+    want = []
+    with CUDACore(w, h, max_batch=T, sample_mat_data=marker) as core:
+        torch.cuda.synchronize()
+        for k in range(K):
+            blk = d_fr[2 * T * k:2 * T * (k + 1)]
+            host = frames[2 * T * k:2 * T * (k + 1)]
+            if k % 2 == 0:   # (0,1), (1,2), ...: cur of a pair is prev of the next
+                RawCore.diff_pairs_batch(core, blk[1:T + 1], blk[0:T], T, *outs[k], T * n)
+                want.append(oracle_pairs(po, host[1:T + 1], host[0:T]))
+            else:            # (0,1), (2,3), ...: a stride of two frames, no frame twice
+                RawCore.diff_pairs_batch(core, blk[1::2], blk[0::2], T, *outs[k], T * n, stride=2 * n)
+                want.append(oracle_pairs(po, host[1::2], host[0::2]))
+        core.synchronize()
+        assert np.array_equal(core.get_state(), marker)
+    for k in range(K):
+        eo, exs, edf = want[k]
+        tot = int(eo[-1])
+        assert np.array_equal(outs[k][0].cpu().numpy().view(np.uint32), eo), k
+        assert np.array_equal(outs[k][1][:tot].cpu().numpy(), exs), k
+        assert np.array_equal(outs[k][2][:tot].cpu().numpy(), edf), k
+
+
 def test_pipelined_1080p_batches_equal_the_sequential_path(po):
     """Full-size overlap: five batches of 65 (odd) 1080p frames queued back to back on the core's own stream -- the
     expansion of batch k runs beside the pack kernel of batch k + 1, two sets of logs in turn, the pack kernel on its
