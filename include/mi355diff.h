@@ -136,12 +136,20 @@ int mi355_set_glyphs(mi355_core *core, const uint8_t *chars_px, int nglyphs, int
  * mi355_int_diff) take frames, not packed streams, and are ordered on the core's stream only: they may run beside
  * the expansion of the batch before (visualiser of frame k + 1 beside the expansion of frame k).  With a caller's
  * stream (mi355_set_stream) nothing is pipelined: every kernel runs on that stream, in call order.
- * MI355_PIPELINE=0 in the environment switches the pipelining off. */
+ * MI355_PIPELINE=0 in the environment switches the pipelining off.  (A pipelined batch is packed by two kernel launches
+ * on two streams of the core, half the tiles each; MI355_SPLIT=0 packs it with one.)
+ * Cache policy: the frames of a stream are read, and every output (d_xs, d_diff, d_wire; the visualiser frames of the
+ * filters) is written, with non-temporal instructions -- each is touched once.  A consumer that reads the packed stream
+ * right behind the batch (mi355_apply_*, the red map, the gather) reads it from memory, not from the caches. */
 int mi355_diff_stream_batch(mi355_core *core, const void *d_frames, size_t stride_bytes, int nframes,
                             void *d_offsets, void *d_xs, void *d_diff, size_t capacity);
 
 /* Stateless form (tests/algorithms_benchmarks.cu style frame pairs): frame t is compared with
- * d_prev + t*stride_bytes instead of the state; the core's state is neither read nor written. */
+ * d_prev + t*stride_bytes instead of the state; the core's state is neither read nor written.
+ * The two operands may overlap in any way (pairs of consecutive frames of one buffer: d_prev = frames,
+ * d_cur = frames + stride).  The library looks at the addresses: operands that share a frame are read through the
+ * caches (the second read of a frame hits), operands that share none -- separate buffers, or the pairs (f - 1, f) of
+ * every 8th f that a round-robin shard diffs -- with non-temporal loads. */
 int mi355_diff_pairs_batch(mi355_core *core, const void *d_cur, const void *d_prev,
                            size_t stride_bytes, int nframes, void *d_offsets, void *d_xs,
                            void *d_diff, size_t capacity);
