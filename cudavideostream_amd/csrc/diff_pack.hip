@@ -603,6 +603,9 @@ __device__ __forceinline__ void lds_handoff() {
 // Measured (profiles/r04an, r04ao): the batch 4-5 % faster on the slower boards of the pool (0.502 -> 0.479 ms) and
 // sequentially (0.537 -> 0.514), unchanged on the fastest; MI355_XNT=0 builds the plain stores.  (Round 1 measured the
 // opposite for its 4-byte + 1-byte scattered stores, r01d: a non-temporal store wants whole 16-byte pieces.)
+#ifndef MI355_XSCALAR_PREFIX
+#define MI355_XSCALAR_PREFIX 1
+#endif
 #ifndef MI355_XNT
 #define MI355_XNT 1
 #endif
@@ -968,9 +971,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const uint32_t tile = sub * kWTiles + lane;
     const __amdgpu_buffer_rsrc_t metas = make_rsrc(a.meta + (size_t)t * a.ntiles, a.ntiles * 16u);
     const u32x4 mq = __builtin_amdgcn_raw_buffer_load_b128(metas, lane < kWTiles ? tile * 16u : kOOB, 0, (MI355_XLOGNT & 4) ? 2 : 0);
+    // The two prefixes are wave-uniform words that only this kernel's LAST step needs (the destination of the stores): they
+    // are read with SCALAR loads (constant address space: nothing writes them while this kernel runs), which leave together
+    // with the meta load and are waited for on their own counter.  As plain loads the compiler placed them behind the
+    // early exit below and waited for them before the code loads left: a fourth dependent round trip in a wave's life
+    // (meta -> prefixes -> codes -> records).
+#if MI355_XSCALAR_PREFIX
+    typedef const __attribute__((address_space(4))) uint32_t *cptr;
+    const cptr offs_c = (cptr)(uintptr_t)a.offsets, roff_c = (cptr)(uintptr_t)a.roff;
+    const uint32_t off_t = offs_c[t];                                           // entries of the frames before t
+    const uint32_t roff = roff_c[(size_t)t * ngroups * 4u + sub];               // entries of frame t before the item's tiles
+    const uint32_t n_t = WIRE ? offs_c[t + 1] - off_t : 0u;                     // entries of frame t
+    asm volatile("" ::"s"(off_t), "s"(roff), "s"(n_t));   // requested HERE, beside the meta load (not behind the early exit below)
+#else
     const uint32_t off_t = a.offsets[t];                                        // entries of the frames before t
     const uint32_t roff = a.roff[(size_t)t * ngroups * 4u + sub];               // entries of frame t before the item's tiles
     const uint32_t n_t = WIRE ? a.offsets[t + 1] - off_t : 0u;                  // entries of frame t
+#endif
     const uint4 m = make_uint4(mq.x, mq.y, mq.z, mq.w);
     size_t head = 0;
     if (WIRE) {
