@@ -697,6 +697,9 @@ constexpr uint32_t kWTiles = 16;             // tiles per item: one DPP row of l
 constexpr uint32_t kWStage = 1024;           // entries of the LDS stage = the most one tile can hold
 constexpr uint32_t kFList = 128;             // most multi-byte lanes of an item on the pair path (queued in 1 KiB of LDS)
 constexpr uint32_t kFStage = kWStage;        // most entries of an item on the pair path (10 bits of a queued lane's word)
+#ifndef MI355_XDENSE_WALK
+#define MI355_XDENSE_WALK 1
+#endif
 #ifndef MI355_XLIGHT
 #define MI355_XLIGHT 4
 #endif
@@ -721,6 +724,20 @@ __device__ __forceinline__ void walk_records(uint32_t m16, uint32_t e, uint32_t 
     const uint32_t cnt = (uint32_t)__builtin_popcount(m16);
     uint64_t heavy = __ballot(cnt > kXLight);
     const uint32_t light_max = __builtin_popcountll(heavy) > kXHeavyMax ? 16u : kXLight;
+    if (MI355_XDENSE_WALK && light_max == 16u) {
+        // DENSE wave (more than kXHeavyMax lanes with more than kXLight bytes: the synthetic worst cases, scene changes): every
+        // lane places its bytes by position, straight code -- byte b of the record goes to e + (flagged bytes below b) if its
+        // bit is set.  7 instructions per byte position and no loop, against 14 per iteration of the bit walk below (which
+        // would run as often as the fullest lane has bytes: 14-16 times here).
+        const uint32_t w[4] = {rec.x, rec.y, rec.z, rec.w};
+        const uint32_t base = src16 << 8;
+#pragma unroll
+        for (uint32_t b = 0; b < 16u; b++) {
+            const uint32_t below = (uint32_t)__builtin_popcount(m16 & ((1u << b) - 1u));
+            if ((m16 >> b) & 1u) stage[e + below] = (base + (b << 8)) | ((w[b >> 2] >> (8u * (b & 3u))) & 0xffu);   // kernels.cu:314-315
+        }
+        return;
+    }
     if (light_max == 16u) heavy = 0;
     if (cnt != 0u && cnt <= light_max) {
         uint32_t mm = m16, ee = e;
