@@ -135,6 +135,8 @@ struct mi355_core {
     int parts = 2;                    // MI355_PARTS=3|4: more launches with equal shares (experiment)
     hipStream_t main2[kMaxParts - 1] = {};
     hipEvent_t packed2[kMaxParts - 1][3] = {};
+    hipEvent_t fork[3] = {};          // recorded on the core's stream in front of a batch's first pack launch: the other parts wait for it
+    int parts_pending = -1;           // log set of the last batch whose parts the core's stream has not waited for (-1: none)
 
     // timing: ring of event sets {before pack, after pack, before scan, after scan, after expand}, harvested lazily
     // so that timed batches still queue back to back
@@ -169,11 +171,19 @@ int dev_alloc(mi355_core *c, T **p, size_t count) {
 // Every entry point starts here.  join: whatever the entry point enqueues on the core's stream (or waits for) comes
 // after the expansion of the last pipelined batch, which runs on the side stream; only the pipelined batch path
 // itself passes false (it orders its own kernels with events).
-int use_device(mi355_core *c, bool join = true) {
+// parts: a pipelined batch is packed by launches on SEVERAL streams (run_batch); whatever follows on the core's stream must
+// not overtake the parts that run elsewhere -- a frame filter that rewrites the buffer the batch is still reading, say.
+// Only the next pipelined batch passes false here too (its own parts queue up behind the last batch's on their streams).
+int use_device(mi355_core *c, bool join = true, bool parts = true) {
     HIP_TRY(hipSetDevice(c->device));
     if (join && c->side_done) {
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->side_done, 0));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->side_done, 0));   // (the expansion waited for every part)
         c->side_done = nullptr;
+        c->parts_pending = -1;
+    }
+    if (parts && c->parts_pending >= 0) {
+        for (int p = 0; p + 1 < c->parts; p++) HIP_TRY(hipStreamWaitEvent(c->stream, c->packed2[p][c->parts_pending], 0));
+        c->parts_pending = -1;
     }
     return MI355_OK;
 }
@@ -421,6 +431,7 @@ int setup_pipeline(mi355_core *c) {
             ok = ok && hipStreamCreateWithFlags(&c->main2[p], hipStreamNonBlocking) == hipSuccess;
             for (int i = 0; i < c->nsets && ok; i++) ok = hipEventCreateWithFlags(&c->packed2[p][i], hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
         }
+        for (int i = 0; i < c->nsets && ok; i++) ok = hipEventCreateWithFlags(&c->fork[i], hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
     }
     for (int i = 0; i < c->nsets && ok; i++) {
         // device-scope release: these events only order kernels of this device against each other.  An event's default
@@ -469,7 +480,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     pipelined = pipelined && !c->fused && !c->chain;
 #endif
     if (pipelined) {
-        if (int rc = use_device(c, false)) return rc;
+        if (int rc = use_device(c, false, false)) return rc;
         if (int rc = setup_pipeline(c)) return rc;
         pipelined = c->pipeline_ok;
     }
@@ -555,6 +566,9 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
         // each part takes its share of the pipelined grid
         const uint32_t P = (uint32_t)c->parts;
         uint32_t begin = 0, blocks_left = c->k1_blocks;
+        // the parts on other streams start behind everything the core's stream holds so far (a filter that is still
+        // writing the frames this batch reads; the upload of the state)
+        HIP_TRY(hipEventRecord(c->fork[c->flip], c->stream));
         for (uint32_t p = 0; p < P; p++) {
             const uint32_t share = P == 2 ? (p == 0 ? (uint32_t)c->split_pct : 100u) : (p + 1u) * 100u / P;   // cumulative per cent
             const uint32_t end = p + 1u == P ? c->ntiles : (uint32_t)((uint64_t)c->ntiles * share / 100u) & ~3u;
@@ -568,6 +582,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
             ap.tile_begin = begin;
             ap.tile_end = end;
             hipStream_t sp = p == 0 ? c->stream : c->main2[p - 1];
+            if (p > 0) HIP_TRY(hipStreamWaitEvent(sp, c->fork[c->flip], 0));
             if (p > 0 && ls.in_use) HIP_TRY(hipStreamWaitEvent(sp, ls.expanded, 0));
             HIP_TRY(launch_diff_pack(ap, pair, aligned, pair_once, blocks, sp));
             if (p > 0) {
@@ -576,6 +591,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
             }
             begin = end;
         }
+        c->parts_pending = c->flip;
     } else {
         HIP_TRY(launch_diff_pack(a, pair, aligned, pair_once, pipelined ? c->k1_blocks : 0u, c->stream));
     }
@@ -730,6 +746,7 @@ void mi355_destroy(mi355_core *c) {
         if (c->side) (void)hipStreamDestroy(c->side);
         for (auto &m : c->main2) if (m) { (void)hipStreamSynchronize(m); (void)hipStreamDestroy(m); }
         for (auto &pe : c->packed2) for (auto &e : pe) if (e) (void)hipEventDestroy(e);
+        for (auto &e : c->fork) if (e) (void)hipEventDestroy(e);
     }
     void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->codes, c->meta, c->groff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
                     c->lut, c->glyphs, c->kxk, c->gray1, c->red_bounds, c->f_wgsum, c->f_sync, c->f_spill, c->f_ovf, c->f_ready, c->c_desc, c->c_status};

@@ -467,6 +467,42 @@ def test_back_to_back_pair_batches_without_synchronisation(po):
         assert np.array_equal(outs[k][2][:tot].cpu().numpy(), edf), k
 
 
+def test_filter_then_diff_on_own_stream_orders_every_part(po):
+    """Config 4's chain on the core's own stream with ONE scratch buffer and no synchronisation in between: the noise filter
+    writes `filt`, the batch's pack kernels -- two launches on two streams of the core -- read it, the next round's filter
+    rewrites it.  Every pack launch has to come behind the filter that made its input (the parts on other streams wait for
+    an event of the core's stream) and the next filter behind every part of the batch before.  Against the oracle, state
+    carried through the filtered frames."""
+    w, h, T, K = 640, 360, 6, 4
+    n = 3 * w * h
+    k9 = po.gaussian_kernel(3, 1.5)
+    base, frames = synth.webcam_stream(T * K, w, h, seed=83)
+    frames = np.ascontiguousarray(frames)
+    filtered = np.stack([po.conv3x3(f, w, h, k9) for f in frames])
+    eo, exs, edf, est = po.diff_stream(filtered, base)
+    d_fr = to_dev(frames)
+    filt = torch.empty((T, n), dtype=torch.uint8, device=DEV)
+    outs = [(torch.zeros(T + 1, dtype=torch.int32, device=DEV), torch.full((T * n,), -7, dtype=torch.int32, device=DEV),
+             torch.zeros(T * n, dtype=torch.uint8, device=DEV)) for _ in range(K)]
+    with CUDACore(w, h, k=k9, max_batch=T, sample_mat_data=base) as core:
+        torch.cuda.synchronize()
+        for k in range(K):
+            RawCore.filter_batch(core, lib.OP_CONV3X3, d_fr[k * T:(k + 1) * T], filt, T)
+            RawCore.diff_stream_batch(core, filt, T, *outs[k], T * n)
+        core.synchronize()
+        assert np.array_equal(core.get_state(), est)
+    per_frame = np.diff(eo.astype(np.int64))
+    at = 0
+    for k in range(K):
+        cnt = per_frame[k * T:(k + 1) * T]
+        off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint32)
+        tot = int(off[-1])
+        assert np.array_equal(outs[k][0].cpu().numpy().view(np.uint32), off), k
+        assert np.array_equal(outs[k][1][:tot].cpu().numpy(), exs[at:at + tot]), k
+        assert np.array_equal(outs[k][2][:tot].cpu().numpy(), edf[at:at + tot]), k
+        at += tot
+
+
 def test_pipelined_1080p_batches_equal_the_sequential_path(po):
     """Full-size overlap: five batches of 65 (odd) 1080p frames queued back to back on the core's own stream -- the
     expansion of batch k runs beside the pack kernel of batch k + 1, two sets of logs in turn, the pack kernel on its
