@@ -503,6 +503,15 @@ def test_filter_then_diff_on_own_stream_orders_every_part(po):
         at += tot
 
 
+def test_chain_soak_short(po):
+    """A short run of tests/soak_chain.py: random sequences of filters, stream and pair batches, red maps and stream switches
+    on one core without host synchronisation inside a round, scratch buffers reused throughout; every output and the state
+    against the oracle."""
+    import soak_chain
+    assert soak_chain.run(12, 5, verbose=False)
+    assert soak_chain.run(4, 6, w=640, h=360, T=4, verbose=False)
+
+
 def test_pipelined_1080p_batches_equal_the_sequential_path(po):
     """Full-size overlap: five batches of 65 (odd) 1080p frames queued back to back on the core's own stream -- the
     expansion of batch k runs beside the pack kernel of batch k + 1, two sets of logs in turn, the pack kernel on its
