@@ -135,6 +135,18 @@ struct mi355_core {
     int parts = 2;                    // MI355_PARTS=3|4: more launches with equal shares (experiment)
     hipStream_t main2[kMaxParts - 1] = {};
     hipEvent_t packed2[kMaxParts - 1][3] = {};
+    // Adaptive overlap: a batch whose expansion is longer than its pack kernel (dense input: a scene change, the synthetic
+    // worst cases) loses by running beside the next batch's pack kernel (S0 pairs 0.313 ms one after the other, 0.35
+    // overlapped).  The batch total (offsets[nframes]) of every own-stream batch is copied to pinned host memory behind its
+    // expansion; the next calls look at the latest total that HAS ARRIVED (hipEventQuery, no waiting) and run one batch after
+    // the other while more than dense_pct per cent of the bytes changed.  Results never depend on it, only the schedule.
+    static constexpr int kTotSlots = 4;
+    uint32_t *h_tot = nullptr;        // pinned, kTotSlots words
+    hipEvent_t tot_ev[kTotSlots] = {};
+    int tot_frames[kTotSlots] = {};
+    uint32_t tot_next = 0;
+    int dense_pct = 40;               // MI355_DENSE_PCT (0: never switch)
+    bool dense = false;               // what the latest total that has arrived said
     hipEvent_t fork[3] = {};          // recorded on the core's stream in front of a batch's first pack launch: the other parts wait for it
     int parts_pending = -1;           // log set of the last batch whose parts the core's stream has not waited for (-1: none)
 
@@ -381,6 +393,7 @@ int setup_pipeline(mi355_core *c) {
     if (const char *b = getenv("MI355_PARTS")) c->parts = atoi(b);
     if (c->parts < 2 || c->parts > mi355_core::kMaxParts) c->parts = 2;
     if (const char *b = getenv("MI355_LOGSETS")) c->nsets = atoi(b) == 3 ? 3 : 2;
+    if (const char *b = getenv("MI355_DENSE_PCT")) c->dense_pct = atoi(b);
     int side_prio = 0;
     if (const char *b = getenv("MI355_SIDE_PRIO")) side_prio = atoi(b);   // 1: the side stream gets the highest stream priority
     const size_t T = (size_t)c->cfg.max_batch, W = c->ntiles;
@@ -433,6 +446,13 @@ int setup_pipeline(mi355_core *c) {
         }
         for (int i = 0; i < c->nsets && ok; i++) ok = hipEventCreateWithFlags(&c->fork[i], hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
     }
+    if (c->dense_pct > 0 && c->dense_pct < 100) {
+        ok = ok && hipHostMalloc((void **)&c->h_tot, mi355_core::kTotSlots * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+        for (int i = 0; i < mi355_core::kTotSlots && ok; i++) {
+            c->h_tot[i] = 0;
+            ok = hipEventCreateWithFlags(&c->tot_ev[i], hipEventDisableTiming) == hipSuccess;
+        }
+    }
     for (int i = 0; i < c->nsets && ok; i++) {
         // device-scope release: these events only order kernels of this device against each other.  An event's default
         // is a SYSTEM-scope fence when it is recorded (caches written back and invalidated for the host's benefit),
@@ -479,10 +499,21 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
 #if MI355_EXPERIMENTS
     pipelined = pipelined && !c->fused && !c->chain;
 #endif
+    const bool own = pipelined;   // an own-stream batch (its total is recorded for the next decisions)
     if (pipelined) {
         if (int rc = use_device(c, false, false)) return rc;
         if (int rc = setup_pipeline(c)) return rc;
         pipelined = c->pipeline_ok;
+    }
+    if (pipelined && c->h_tot) {
+        // the latest batch total that has arrived: dense input -> this batch runs after the expansion of the one before
+        for (uint32_t k = 1; k <= (uint32_t)mi355_core::kTotSlots && k <= c->tot_next; k++) {
+            const uint32_t slot = (c->tot_next - k) % mi355_core::kTotSlots;
+            if (hipEventQuery(c->tot_ev[slot]) != hipSuccess) continue;
+            c->dense = (uint64_t)c->h_tot[slot] * 100u > (uint64_t)c->dense_pct * (uint64_t)c->tot_frames[slot] * c->n;
+            break;
+        }
+        if (c->dense) pipelined = false;   // (no total has arrived since the last look: what the last one said still holds)
     }
     if (!pipelined)
         if (int rc = use_device(c)) return rc;
@@ -633,6 +664,13 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
         HIP_TRY(hipEventRecord(tev[4], tail));
         c->ev_count += 1;
     }
+    if (own && c->h_tot && c->pipeline_ok) {
+        const uint32_t slot = c->tot_next % mi355_core::kTotSlots;
+        HIP_TRY(hipMemcpyAsync(&c->h_tot[slot], (const uint32_t *)d_offsets + nframes, sizeof(uint32_t), hipMemcpyDeviceToHost, tail));
+        HIP_TRY(hipEventRecord(c->tot_ev[slot], tail));
+        c->tot_frames[slot] = nframes;
+        c->tot_next += 1;
+    }
     if (pipelined) {
         HIP_TRY(hipEventRecord(ls.expanded, tail));
         ls.in_use = true;
@@ -747,6 +785,8 @@ void mi355_destroy(mi355_core *c) {
         for (auto &m : c->main2) if (m) { (void)hipStreamSynchronize(m); (void)hipStreamDestroy(m); }
         for (auto &pe : c->packed2) for (auto &e : pe) if (e) (void)hipEventDestroy(e);
         for (auto &e : c->fork) if (e) (void)hipEventDestroy(e);
+        for (auto &e : c->tot_ev) if (e) (void)hipEventDestroy(e);
+        if (c->h_tot) (void)hipHostFree(c->h_tot);
     }
     void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->codes, c->meta, c->groff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
                     c->lut, c->glyphs, c->kxk, c->gray1, c->red_bounds, c->f_wgsum, c->f_sync, c->f_spill, c->f_ovf, c->f_ready, c->c_desc, c->c_status};

@@ -138,6 +138,10 @@ int mi355_set_glyphs(mi355_core *core, const uint8_t *chars_px, int nglyphs, int
  * stream (mi355_set_stream) nothing is pipelined: every kernel runs on that stream, in call order.
  * MI355_PIPELINE=0 in the environment switches the pipelining off.  (A pipelined batch is packed by two kernel launches
  * on two streams of the core, half the tiles each; MI355_SPLIT=0 packs it with one.)
+ * The overlap is adaptive: a batch in which more than 40 % of the bytes changed (a scene change; MI355_DENSE_PCT) has an
+ * expansion longer than its pack kernel and loses by running beside the next batch.  The library copies every own-stream
+ * batch's total to pinned host memory behind its expansion and, without ever waiting for it, runs batches one after the
+ * other while the latest total that has arrived says "dense".  Only the schedule depends on it, never a result.
  * Cache policy: the frames of a stream are read, and every output (d_xs, d_diff, d_wire; the visualiser frames of the
  * filters) is written, with non-temporal instructions -- each is touched once.  A consumer that reads the packed stream
  * right behind the batch (mi355_apply_*, the red map, the gather) reads it from memory, not from the caches. */

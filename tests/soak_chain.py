@@ -2,7 +2,8 @@
 """Chain soak (not part of the test suite; tests/test_diff_pack_gpu.py runs a short one): random sequences of entry points on
 ONE long-lived core, queued on the core's own stream WITHOUT host synchronisation between them, through a few scratch
 buffers that are reused all the time -- frame filter into a scratch, stream batch out of that scratch, pair batches of
-both operand forms, the red map of a batch's packed stream, switches between the core's stream and a caller's.  A round
+both operand forms, dense batches (after which the library stops overlapping batches until the input is sparse again),
+the red map of a batch's packed stream, switches between the core's stream and a caller's.  A round
 is synchronised once at its end and every output of the round compared with the oracle.  What it is after: ordering
 between the streams a pipelined batch uses inside the library (core.hip, run_batch / use_device), not arithmetic.
     python tests/soak_chain.py [rounds] [seed]      exits non-zero on the first mismatch"""
@@ -36,6 +37,8 @@ def run(rounds, seed, w=320, h=180, T=5, verbose=True):
     base, pool = synth.webcam_stream(64, w, h, seed=seed + 1)
     pool = np.ascontiguousarray(pool)
     d_pool = torch.from_numpy(pool).to(DEV)
+    noise = rng.integers(0, 256, (2 * T, n), dtype=np.uint8)   # dense input: nearly every byte changes (the library then stops
+    d_noise = torch.from_numpy(noise).to(DEV)                  # overlapping batches once such a batch's total has arrived)
     scratch = torch.empty((T, n), dtype=torch.uint8, device=DEV)      # filter output = batch input, rewritten every time
     vis = torch.empty((T, n), dtype=torch.uint8, device=DEV)
     nout = 6
@@ -50,7 +53,7 @@ def run(rounds, seed, w=320, h=180, T=5, verbose=True):
         nops = int(rng.integers(2, nout + 1))
         torch.cuda.synchronize()
         for i in range(nops):
-            op = int(rng.integers(0, 6))
+            op = int(rng.integers(0, 7))
             f0 = int(rng.integers(0, 64 - 2 * T))
             o = outs[i]
             if op == 0:      # stream batch straight from the pool
@@ -77,6 +80,11 @@ def run(rounds, seed, w=320, h=180, T=5, verbose=True):
                 red_expect = np.zeros((T, n), np.uint8)
                 for t in range(T):
                     red_expect[t] = po.red_overlap(red_expect[t], exs[eo[t]:eo[t + 1]])
+            elif op == 6:    # a dense stream batch
+                g0 = int(rng.integers(0, T + 1))
+                core.diff_stream_batch(d_noise[g0:g0 + T], T, *o, T * n)
+                eo, exs, edf, state = po.diff_stream(noise[g0:g0 + T], state)
+                checks.append(("dense stream", o, (eo, exs, edf)))
             else:            # switch streams (a synchronising call by contract)
                 own = not own
                 (core.use_own_stream if own else core.use_torch_stream)()
