@@ -147,6 +147,8 @@ struct mi355_core {
     uint32_t tot_next = 0;
     int dense_pct = 40;               // MI355_DENSE_PCT (0: never switch)
     bool dense = false;               // what the latest total that has arrived said
+    bool filter_since_batch = false;  // a frame filter ran on this core since the last batch (use_device_filter)
+    bool chain_hint = true;           // MI355_CHAIN_HINT=0 at mi355_create: batches are overlapped regardless
     hipEvent_t fork[3] = {};          // recorded on the core's stream in front of a batch's first pack launch: the other parts wait for it
     int parts_pending = -1;           // log set of the last batch whose parts the core's stream has not waited for (-1: none)
 
@@ -198,6 +200,17 @@ int use_device(mi355_core *c, bool join = true, bool parts = true) {
         c->parts_pending = -1;
     }
     return MI355_OK;
+}
+
+// A frame filter takes frames, not packed streams: it does not wait for a pipelined batch that is still expanding on the
+// side stream.  It leaves a hint, though: a caller that alternates filters and batches (the server's visualiser or noise
+// filter in front of every diff: BASELINE configs 3 and 4) gains nothing from a batch's expansion running beside the next
+// filter -- both are bound by the memory system -- and loses the pipelined batch's smaller pack grid and stream hops:
+// 4.6 us per frame one after the other, 5.0-5.2 overlapped (config 3, profiles/r04bd).  The next batch therefore runs one
+// kernel after the other on the core's stream (MI355_CHAIN_HINT=0: ignore the hint).
+int use_device_filter(mi355_core *c) {
+    c->filter_since_batch = c->chain_hint;
+    return use_device(c, false);
 }
 
 // Fold pending event sets into the sums: all of them (blocking) or only until `keep` remain.
@@ -500,6 +513,8 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     pipelined = pipelined && !c->fused && !c->chain;
 #endif
     const bool own = pipelined;   // an own-stream batch (its total is recorded for the next decisions)
+    if (c->filter_since_batch) pipelined = false;   // a filter / batch chain: one kernel after the other (use_device_filter)
+    c->filter_since_batch = false;
     if (pipelined) {
         if (int rc = use_device(c, false, false)) return rc;
         if (int rc = setup_pipeline(c)) return rc;
@@ -720,6 +735,7 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     mi355_core *c = new (std::nothrow) mi355_core;
     if (!c) return fail(MI355_ERR_INVALID, "out of host memory");
     c->cfg = *cfg;
+    if (const char *v = getenv("MI355_CHAIN_HINT")) c->chain_hint = v[0] != '0';
     if (cfg->device >= 0) c->device = cfg->device;
     else if ((e = hipGetDevice(&c->device)) != hipSuccess) { delete c; return fail(MI355_ERR_HIP, "hipGetDevice", e); }
     if (c->device >= ndev) { delete c; return fail(MI355_ERR_INVALID, "device ordinal out of range"); }
@@ -980,28 +996,28 @@ int mi355_merge_parts(mi355_core *c, int nparts, int nframes, const void *d_part
 
 int mi355_int_diff(mi355_core *c, const void *d_cur, const void *d_prev, void *d_out, size_t n) {
     if (!c || (n && (!d_cur || !d_prev || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
-    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
+    if (int rc = use_device_filter(c)) return rc;
     HIP_TRY(launch_int_diff((const int32_t *)d_cur, (const int32_t *)d_prev, (int32_t *)d_out, n, c->stream));
     return MI355_OK;
 }
 
 int mi355_gray_avg(mi355_core *c, const void *d_in, void *d_out) {
     if (!c || (c->n && (!d_in || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
-    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
+    if (int rc = use_device_filter(c)) return rc;
     HIP_TRY(launch_gray((const uint8_t *)d_in, (uint8_t *)d_out, c->n / 3, false, FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
 }
 
 int mi355_gray_weighted(mi355_core *c, const void *d_in, void *d_out) {
     if (!c || (c->n && (!d_in || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
-    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
+    if (int rc = use_device_filter(c)) return rc;
     HIP_TRY(launch_gray((const uint8_t *)d_in, (uint8_t *)d_out, c->n / 3, true, FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
 }
 
 int mi355_binarize_chain(mi355_core *c, const void *d_gray, void *d_out, void *d_hist, void *d_thr) {
     if (!c || (c->n && (!d_gray || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
-    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
+    if (int rc = use_device_filter(c)) return rc;
     int32_t *hist = d_hist ? (int32_t *)d_hist : c->hist;
     int32_t *thr = d_thr ? (int32_t *)d_thr : c->thr;
     HIP_TRY(launch_binarize_chain((const uint8_t *)d_gray, (uint8_t *)d_out, c->n, hist, thr, FrameBatch{c->n, 1}, c->stream));
@@ -1010,7 +1026,7 @@ int mi355_binarize_chain(mi355_core *c, const void *d_gray, void *d_out, void *d
 
 int mi355_heat_map(mi355_core *c, const void *d_cur, const void *d_prev, void *d_out) {
     if (!c || (c->n && (!d_cur || !d_prev || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
-    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
+    if (int rc = use_device_filter(c)) return rc;
     HIP_TRY(launch_heat_map((const uint8_t *)d_cur, (const uint8_t *)d_prev, (uint8_t *)d_out, c->n / 3,
                             c->lut, FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
@@ -1018,7 +1034,7 @@ int mi355_heat_map(mi355_core *c, const void *d_cur, const void *d_prev, void *d
 
 int mi355_red_dense(mi355_core *c, const void *d_cur, const void *d_prev, void *d_out) {
     if (!c || (c->n && (!d_cur || !d_prev || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
-    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
+    if (int rc = use_device_filter(c)) return rc;
     HIP_TRY(launch_red_dense((const uint8_t *)d_cur, (const uint8_t *)d_prev, (uint8_t *)d_out, c->n / 3,
                              c->cfg.threshold, FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
@@ -1053,7 +1069,7 @@ int mi355_conv3x3(mi355_core *c, const void *d_in, void *d_out) {
     if (!c || (c->n && (!d_in || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
     if (d_in == d_out && c->n) return fail(MI355_ERR_INVALID, "conv3x3 cannot run in place");
     if (!c->have_k9) return fail(MI355_ERR_STATE, "mi355_set_conv_kernel not called");
-    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
+    if (int rc = use_device_filter(c)) return rc;
     HIP_TRY(launch_conv3x3((const uint8_t *)d_in, (uint8_t *)d_out, c->cfg.width, c->cfg.height, c->k9,
                            c->k9_sym, FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
@@ -1063,7 +1079,7 @@ int mi355_conv_kxk(mi355_core *c, const void *d_in, void *d_out, const float *k,
     if (!c || !k || (c->n && (!d_in || !d_out))) return fail(MI355_ERR_INVALID, "null argument");
     if (K < 1 || K > 9) return fail(MI355_ERR_INVALID, "K outside [1, 9]");
     if (d_in == d_out && c->n) return fail(MI355_ERR_INVALID, "conv_kxk cannot run in place");
-    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
+    if (int rc = use_device_filter(c)) return rc;
     if (!c->kxk)
         if (int rc = dev_alloc(c, &c->kxk, 81)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));    // a filter of an earlier call may still be reading the taps
@@ -1077,7 +1093,7 @@ int mi355_conv_kxk(mi355_core *c, const void *d_in, void *d_out, const float *k,
 int mi355_median5x5(mi355_core *c, const void *d_in, void *d_out) {
     if (!c || !d_in || !d_out) return fail(MI355_ERR_INVALID, "null argument");
     if (d_in == d_out) return fail(MI355_ERR_INVALID, "median is not in-place");
-    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
+    if (int rc = use_device_filter(c)) return rc;
     HIP_TRY(launch_median5x5((const uint8_t *)d_in, (uint8_t *)d_out, c->cfg.width, c->cfg.height,
                              FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
@@ -1095,7 +1111,7 @@ int mi355_filter_batch(mi355_core *c, int op, const void *d_in, const void *d_in
     if (op == MI355_OP_CONV3X3 && !c->have_k9) return fail(MI355_ERR_STATE, "mi355_set_conv_kernel not called");
     if ((op == MI355_OP_CONV3X3 || op == MI355_OP_MEDIAN5X5) && d_in == d_out)
         return fail(MI355_ERR_INVALID, "neighbourhood filters cannot run in place");
-    if (int rc = use_device(c, false)) return rc;   // a frame filter: independent of a pipelined batch still expanding
+    if (int rc = use_device_filter(c)) return rc;
     const uint8_t *in = (const uint8_t *)d_in, *in2 = (const uint8_t *)d_in2;
     uint8_t *out = (uint8_t *)d_out;
     const FrameBatch fb{stride_bytes, nframes};

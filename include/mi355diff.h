@@ -138,6 +138,9 @@ int mi355_set_glyphs(mi355_core *core, const uint8_t *chars_px, int nglyphs, int
  * stream (mi355_set_stream) nothing is pipelined: every kernel runs on that stream, in call order.
  * MI355_PIPELINE=0 in the environment switches the pipelining off.  (A pipelined batch is packed by two kernel launches
  * on two streams of the core, half the tiles each; MI355_SPLIT=0 packs it with one.)
+ * A batch that follows a frame filter on this core (the server's visualiser or noise filter in front of every diff) is not
+ * overlapped either: one kernel after the other measured faster for such chains (MI355_CHAIN_HINT=0 when the core is
+ * created: overlap regardless).
  * The overlap is adaptive: a batch in which more than 40 % of the bytes changed (a scene change; MI355_DENSE_PCT) has an
  * expansion longer than its pack kernel and loses by running beside the next batch.  The library copies every own-stream
  * batch's total to pinned host memory behind its expansion and, without ever waiting for it, runs batches one after the
