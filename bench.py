@@ -171,6 +171,12 @@ def parse():
                         "form of the exchange instead of failing (the line then says so in config.gather_impl)")
     p.add_argument("--gather-every-steps", type=int, default=10,
                    help="N > 1: steps of the secondary `gather_every` measurement (a gather after EVERY batch)")
+    p.add_argument("--rehearse-on-one-gpu", action="store_true",
+                   help="NOT a measurement: run the N-rank job with every rank on device 0 -- one process per rank, "
+                        "torch.distributed over gloo, the exchange below the C-ABI through the tests' inter-process "
+                        "stand-in for RCCL (tests/mock_rccl/librccl_mock_ipc.so; real RCCL refuses two ranks on one "
+                        "device) -- to prove the process-per-rank sequence before the first run on an 8-GPU node")
+    p.add_argument("--no-config5", action="store_true", help="skip the config5_per_gpu object (4K round-robin shard on one GPU)")
     return p.parse_args()
 
 
@@ -211,15 +217,23 @@ def cpu_baseline(args, base, frames, dev):
             L.ora_diff_pack(h_frames[t], st, n, 20, xs, df)
         done += B
     dt = time.perf_counter() - t0
-    # timing: all host cores (row bands, identical output)
+    # timing: ALL host cores -- a row band per thread for all frames of a sub-batch (a band's state belongs to its thread:
+    # the threads are started once per sub-batch, not per frame), pieces put together in (frame, band) order: output
+    # identical to the single-threaded loop (tests/test_oracle.py::test_stream_mt_matches_single_thread)
     ncores = os.cpu_count() or 1
-    nthr = min(ncores, 32)
+    nthr = max(1, min(ncores, 1024))
+    SB = min(B, 64)
     st = h_base.copy()
+    cap_mt = SB * n
+    xs_mt = np.empty(cap_mt, np.int32)
+    df_mt = np.empty(cap_mt, np.uint8)
+    off_mt = np.zeros(SB + 1, np.uint32)
+    sub = np.ascontiguousarray(h_frames[:SB]).reshape(-1)
     done_mt, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < min(3.0, args.cpu_seconds):
-        for t in range(min(B, 32)):
-            L.ora_diff_pack_mt(h_frames[t], st, n, 20, xs, df, nthr)
-        done_mt += min(B, 32)
+    while time.perf_counter() - t0 < min(4.0, args.cpu_seconds):
+        rc = L.ora_diff_stream_mt(sub, SB, st, n, 20, off_mt, xs_mt, df_mt, cap_mt, nthr)
+        assert rc == 0, rc
+        done_mt += SB
     dt_mt = time.perf_counter() - t0
     base_obj = {"value": round(done / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                 "sample": f"{done} frames ({done // B} passes over the batch's {B} frames of the same "
@@ -227,7 +241,8 @@ def cpu_baseline(args, base, frames, dev):
                           f"ora_diff_pack, {dt:.1f} s",
                 "all_cores": {"value": round(done_mt / dt_mt, 2), "unit": "frames/s", "cores": nthr,
                               "host_cores": ncores,
-                              "sample": f"{done_mt} frames, row-band pthreads, {dt_mt:.1f} s"}}
+                              "sample": f"{done_mt} frames ({SB}-frame sub-batches, one row band per thread for the "
+                                        f"whole sub-batch, {nthr} threads on {ncores} host cores), {dt_mt:.1f} s"}}
     ref = reference_filter_chain(args, h_base, h_frames)
     if ref:
         base_obj["reference_filter_chain"] = ref
@@ -360,7 +375,28 @@ def spawn_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    return subprocess.run(cmd, env=env).returncode
+    shm = None
+    if args.rehearse_on_one_gpu:
+        env.update(rehearsal_env())
+        shm = env["MOCK_RCCL_SHM"]
+    try:
+        return subprocess.run(cmd, env=env).returncode
+    finally:
+        if shm:
+            try:
+                os.unlink("/dev/shm" + shm)
+            except OSError:
+                pass
+
+
+def rehearsal_env():
+    """Environment of a --rehearse-on-one-gpu job: the inter-process stand-in for RCCL and the shared-memory object its
+    ranks meet in (an existing MOCK_RCCL_SHM -- a test's -- is kept)."""
+    mock = os.path.join(ROOT, "tests", "mock_rccl", "librccl_mock_ipc.so")
+    if not os.path.exists(mock):
+        raise SystemExit(f"bench.py --rehearse-on-one-gpu: {mock} is missing (python -c 'import __graft_entry__ as g; g.build()')")
+    return {"MI355_RCCL_LIB": os.environ.get("MI355_RCCL_LIB", mock),
+            "MOCK_RCCL_SHM": os.environ.get("MOCK_RCCL_SHM", f"/mi355bench_{os.getpid()}")}
 
 
 def main():
@@ -377,12 +413,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+    rehearse = args.rehearse_on_one_gpu
+    if rehearse:
+        local_rank = 0   # every rank on the one GPU
+        if "MI355_RCCL_LIB" not in os.environ or "MOCK_RCCL_SHM" not in os.environ:
+            raise SystemExit("bench.py --rehearse-on-one-gpu under a launcher of your own: export MI355_RCCL_LIB="
+                             "tests/mock_rccl/librccl_mock_ipc.so and MOCK_RCCL_SHM=/some_name for all ranks "
+                             "(`python bench.py --gpus N --rehearse-on-one-gpu` does it by itself)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    # tensors torch.distributed moves: on the device with RCCL, on the host with gloo (the rehearsal)
+    cdev = torch.device("cpu") if rehearse else dev
     if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run (also at N = 1)
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
@@ -413,12 +461,18 @@ def main():
     # torch.distributed hands around.  If the group cannot be formed (a harness matter, not the path's), the
     # torch.distributed form of the same exchange (cudavideostream_amd/gather.py) is used and named in the line.
     group, gather_impl = None, "n/a"
-    if world > 1 and args.gather != "none":
-        gather_impl = "mi355_group_gather (RCCL, csrc/group.hip)"
+    # (under a launcher the group is formed at N = 1 too: the line then carries ranks_seen / gather_ms / gather_bytes of
+    # the same code path the N > 1 runs take)
+    if dist is not None and args.gather != "none":
+        gather_impl = ("mi355_group_gather (csrc/group.hip) over the tests' inter-process stand-in for RCCL: REHEARSAL"
+                       if rehearse else "mi355_group_gather (RCCL, csrc/group.hip)")
+        stage = "mi355_group_unique_id"
         try:
             from cudavideostream_amd.group import CUDAGroup, unique_id
-            ident = torch.from_numpy(unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(dev)
+            ident = torch.from_numpy(unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(cdev)
+            stage = "torch.distributed broadcast of the id"
             dist.broadcast(ident, src=0)
+            stage = "mi355_group_adopt_rank"
             group = CUDAGroup.adopt(core, world, rank, ident.cpu().numpy())
             root_cap = world * cap if rank == 0 else 0
             r_off = torch.zeros((world, B + 1), dtype=torch.int32, device=dev) if rank == 0 else None
@@ -427,7 +481,11 @@ def main():
         except Exception as e:   # noqa: BLE001
             group = None
             gather_impl = f"torch.distributed (mi355_group unavailable: {repr(e)[:100]})"
-        ok = torch.tensor([1 if group is not None else 0], device=dev)
+            # WHICH step failed, on WHICH rank, with the library's own text (it names the RCCL entry point:
+            # csrc/group.hip RCCL_TRY) -- before anything else happens to this process
+            print(f"bench.py: rank {rank} of {world} (device {local_rank}): forming the group failed in {stage}: {e!r}",
+                  file=sys.stderr, flush=True)
+        ok = torch.tensor([1 if group is not None else 0], device=cdev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank takes the same way
         if int(ok.item()) == 0 and group is not None:
             group.close()
@@ -435,10 +493,10 @@ def main():
             gather_impl = "torch.distributed (mi355_group unavailable on another rank)"
         if group is None:
             core.use_torch_stream()   # the torch.distributed form of the exchange runs on torch's stream
-        if group is None and not args.allow_gather_fallback:
+        if group is None and (not args.allow_gather_fallback or rehearse):
             # a scaling line must measure the path's own exchange: no silent change of what is timed
             print(f"bench.py: rank {rank}: the RCCL group could not be formed ({gather_impl}); "
-                  f"--allow-gather-fallback measures the torch.distributed form instead", file=sys.stderr)
+                  f"--allow-gather-fallback measures the torch.distributed form instead", file=sys.stderr, flush=True)
             dist.barrier()
             dist.destroy_process_group()
             raise SystemExit(3)
@@ -467,7 +525,7 @@ def main():
             core.diff_pairs_batch(frames, prevs, B, d_off, d_xs, d_df, cap)
         else:
             core.diff_stream_batch(frames, B, d_off, d_xs, d_df, cap)
-        if world > 1:
+        if dist is not None and args.gather != "none":
             # the path itself has no collective (independent streams); the one exchange step is the gather
             # of the changed-pixel stream to rank 0: of the final batch ("last", the default), of every
             # batch ("every"), or the per-frame index every step and the payload at the end ("index")
@@ -495,18 +553,18 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     ms_pack, ms_scan, ms_expand, launches = core.get_kernel_timing()
     core.set_timing(False)
-    pipelined = os.environ.get("MI355_PIPELINE", "1") != "0" and (group is not None or world == 1 or args.gather == "none")
+    pipelined = core.get_option(1) == 1 and (group is not None or dist is None or args.gather == "none")
     g_last = dict(gstat)
     # secondary measurement (N > 1): the same job with the gather after EVERY batch -- the exchange at its worst
     # (every byte of every rank funnelled to one GPU), so that the scaling curve shows what the gather costs
     g_every = None
-    if world > 1 and args.gather != "none" and args.gather_every_steps > 0:
+    if world > 1 and group is not None and args.gather_every_steps > 0:
         gstat.update(ms=0.0, calls=0, bytes=0)
         K2 = args.gather_every_steps
         dist.barrier()
@@ -520,7 +578,7 @@ def main():
             exchange_payload()
         torch.cuda.synchronize()
         dist.barrier()
-        e2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        e2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=cdev)
         dist.all_reduce(e2, op=dist.ReduceOp.MAX)
         e2 = float(e2.item())
         g_every = {"value": round(world * B * K2 / e2, 1), "unit": "frames/s", "steps": K2,
@@ -532,6 +590,28 @@ def main():
     off = d_off.cpu().numpy().view(np.uint32)
     p_total = int(off[-1])
     assert p_total <= cap, "output capacity too small for this stream"
+
+    # Did the root receive what the ranks produced?  (Outside every timed region.)  The last thing every rank did was a
+    # gather of its latest batch: every rank digests its own (offsets, xs, diff), the digests travel over
+    # torch.distributed, rank 0 digests the segment it holds for every rank.
+    gather_verified = None
+    if group is not None:
+        def digest(o, xs, df):
+            pn = int(o[-1].item()) & 0xFFFFFFFF
+            w = torch.arange(pn, device=dev, dtype=torch.int64) % 8191 + 1
+            return [pn, int(o.to(torch.int64).sum().item()), int((xs[:pn].to(torch.int64) * w).sum().item()),
+                    int((df[:pn].to(torch.int64) * w).sum().item())]
+        core.synchronize()
+        mine_d = torch.tensor(digest(d_off, d_xs, d_df), dtype=torch.int64, device=cdev)
+        all_d = [torch.zeros_like(mine_d) for _ in range(world)]
+        dist.all_gather(all_d, mine_d)
+        if rank == 0:
+            gather_verified, at = True, 0
+            for r in range(world):
+                pn = int(all_d[r][0].item())
+                got = digest(r_off[r], r_xs[at:], r_df[at:]) if at + pn <= r_xs.numel() else None
+                gather_verified = gather_verified and got == [int(v) for v in all_d[r].tolist()]
+                at += pn
 
     if rank == 0:
         alg_bytes = 2.0 * n * B + 5.0 * p_total          # B_alg = 2N + 5P per frame
@@ -549,6 +629,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
+            **({"rehearsal": "NOT A MEASUREMENT: every rank ran on device 0 (torch.distributed over gloo, the exchange "
+                             "through tests/mock_rccl/librccl_mock_ipc.so, payloads staged through host shared memory)"}
+               if rehearse else {}),
             "config": {"workload": (f"{W}x{H} BGR24 S1 webcam sequence dealt round-robin to the ranks, {B}-frame "
                                     f"batches resident in HBM, stateless diff against the raw predecessor"
                                     f"+threshold(20)+pack, ordered output" if rr else
@@ -557,11 +640,12 @@ def main():
                        "frames_per_step": B, "changed_bytes_per_frame": round(p_total / B, 1),
                        "parallelism": (f"frames round-robin over {world} ranks" if rr else
                                        f"{world} independent streams" if world > 1 else "1 stream"),
-                       "gather": args.gather if world > 1 else "n/a", "gather_impl": gather_impl},
+                       "gather": args.gather if dist is not None else "n/a", "gather_impl": gather_impl},
             "ranks_seen": g_last["ranks_seen"],
             "gather_ms": round(g_last["ms"] / g_last["calls"], 4) if g_last["calls"] else None,
             "gather_bytes": g_last["bytes"] // g_last["calls"] if g_last["calls"] else None,
             "gather_every": g_every,
+            "gather_verified": gather_verified,
             "roofline": path_roofline(alg_bytes, (ms_pack, ms_scan, ms_expand), launches, rr, pmc,
                                       wall_ms=elapsed / K * 1e3 if pipelined else None),
         }
@@ -572,6 +656,8 @@ def main():
             out["two_streams_one_gpu"] = two_streams(args, core, frames, base, d_off, d_xs, d_df, cap, dev)
         if world == 1 and not args.no_filters and not rr:
             out.update(filter_configs(args, dev))
+        if world == 1 and not args.no_config5 and not rr and (W, H) == (1920, 1080):
+            out["config5_per_gpu"] = config5_per_gpu(args, dev)
         if world == 1 and not args.no_host_path:
             out["host_path"] = host_path(args, base, frames)
         out["board"] = board_fingerprint(core, "right after the timed region")
@@ -584,6 +670,8 @@ def main():
             par = {"headline": headline_ok}
             if not args.no_pair or not args.no_filters:
                 par.update(parity_of_secondary_lines(args, dev, frames))
+            if isinstance(out.get("config5_per_gpu"), dict) and "parity" in out["config5_per_gpu"]:
+                par["config5_per_gpu"] = out["config5_per_gpu"]["parity"]
             out["parity"] = par
             parity_failed = not all(par.values())
         else:
@@ -711,17 +799,17 @@ def path_line(B, n, p, sec_per_call, ms, launches, pair, sec_pipelined=None):
            "achieved_gbps": r["achieved"], "frac": r["frac"],
            "kernels_us": [k["avg_us"] for k in r["kernels"]]}
     if sec_pipelined is not None:
-        # both ways of calling the library are the product (mi355diff.h, "Streams"); the line's `frac` is the better one
-        # of the two and says which: webcam-like pairs gain from the overlap, the dense regimes (expansion three times
-        # as long as the pack kernel, 32-frame batches) lose by it
+        # ONE method for `frac`, the headline's: the calls on the core's OWN stream, wall clock per call (the library's
+        # default way of running: batches overlapped unless its adaptive overlap sees dense input and runs them one after
+        # the other by itself).  The caller's-stream figure (kernels' own durations added up) stays under its own keys.
         gbps = alg / sec_pipelined / 1e9
-        out.update({"frac_sequential": r["frac"], "frac_pipelined": round(gbps / HBM_PEAK_GBPS, 4),
-                    "ms_per_launch_pipelined": round(sec_pipelined * 1e3, 4)})
-        if gbps / HBM_PEAK_GBPS > r["frac"]:
-            out.update({"frac": round(gbps / HBM_PEAK_GBPS, 4), "achieved_gbps": round(gbps, 1), "mode": "pipelined (the core's own stream)",
-                        "frames_per_s": round(B / sec_pipelined, 1)})
-        else:
-            out["mode"] = "sequential (a caller's stream)"
+        out.update({"frac_sequential": r["frac"], "achieved_gbps_sequential": r["achieved"],
+                    "frames_per_s_sequential": out["frames_per_s"],
+                    "frac": round(gbps / HBM_PEAK_GBPS, 4), "achieved_gbps": round(gbps, 1),
+                    "frames_per_s": round(B / sec_pipelined, 1), "ms_per_launch": round(sec_pipelined * 1e3, 4),
+                    "basis": "frac / frames_per_s / ms_per_launch: the core's own stream, wall clock per call (as the "
+                             "headline); *_sequential, all_kernels_ms, kernels_us: a caller's stream, HIP-event "
+                             "durations of the three kernels added up"})
     return out
 
 
@@ -770,6 +858,44 @@ def two_streams(args, core, frames, base, d_off, d_xs, d_df, cap, dev, reps=20):
         return {"frames_per_s": round(2 * B / dt, 1), "ms_per_round_of_two_batches": round(dt * 1e3, 4),
                 "frac": round(alg / dt / 1e9 / HBM_PEAK_GBPS, 4),
                 "note": "two cores, two streams, 2 x %d frames per round; wall clock" % B}
+    except Exception as e:   # noqa: BLE001  -- a secondary line must not cost the bench line (memory on a shared box)
+        return {"skipped": repr(e)[:160]}
+
+
+def config5_per_gpu(args, dev, ranks=8, B=64, W=3840, H=2160, reps=10):
+    """BASELINE configs[4] as ONE GPU of the 8 sees it: a 4K S1 sequence dealt round-robin over 8 ranks, this rank's
+    64-frame shard (frames 0, 8, 16, ...) diffed against their raw predecessors, stateless (mi355_diff_pairs_batch;
+    the operands share no frame, so both are read with non-temporal loads).  Same measurement as `pair_mode`; parity of
+    the first and the last pair of the shard against the oracle."""
+    from oracle import pyoracle as po
+    n = 3 * W * H
+    mine = gx.roundrobin_frames(0, ranks, B * ranks)
+    try:
+        frames = torch.stack([synth.webcam_frame(t, W, H, seed=31, device=dev) for t in mine])
+        prevs = torch.stack([synth.webcam_frame(t - 1, W, H, seed=31, device=dev) for t in mine])
+        cap = max(B * n // 8, 1 << 20)
+        d_off = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+        d_xs = torch.empty(cap, dtype=torch.int32, device=dev)
+        d_df = torch.empty(cap, dtype=torch.uint8, device=dev)
+        with CUDACore(W, H, max_batch=B) as core:
+            torch.cuda.synchronize()
+            core.use_torch_stream()
+            sec, ms, launches = timed_path(core, lambda: core.diff_pairs_batch(frames, prevs, B, d_off, d_xs, d_df, cap), reps)
+            core.use_own_stream()
+            sec_pipe = wall_per_call(core, lambda: core.diff_pairs_batch(frames, prevs, B, d_off, d_xs, d_df, cap), reps)
+            off = d_off.cpu().numpy().view(np.uint32)
+            p = int(off[B])
+            assert p <= cap, "config5_per_gpu: output capacity too small"
+            out = path_line(B, n, p, sec, ms, launches, True, sec_pipe)
+            ok = True
+            for t in (0, B - 1):
+                cnt, xs, df, _ = po.diff_pack(frames[t].cpu().numpy(), prevs[t].cpu().numpy())
+                ok = ok and int(off[t + 1] - off[t]) == cnt and np.array_equal(d_xs[int(off[t]):int(off[t + 1])].cpu().numpy(), xs) \
+                    and np.array_equal(d_df[int(off[t]):int(off[t + 1])].cpu().numpy(), df)
+        out.update({"workload": f"BASELINE configs[4], one GPU's share: {W}x{H} BGR24 S1 sequence dealt round-robin over {ranks} "
+                                f"ranks, rank 0's {B}-frame shard, stateless diff against the raw predecessor + threshold(20) + pack",
+                    "parity": bool(ok)})
+        return out
     except Exception as e:   # noqa: BLE001  -- a secondary line must not cost the bench line (memory on a shared box)
         return {"skipped": repr(e)[:160]}
 

@@ -54,16 +54,22 @@ class CUDACore:
 
     def __init__(self, width, height, k=None, sample_mat_data=None, chars_px=None, chars_sz=None,
                  charset=CHARS_STR, threshold=LR_THRESHOLDS, max_batch=1, device=-1,
-                 noise_filter=False, visualizer=_l.VIS_NONE, fused=False, chain=False):
+                 noise_filter=False, visualizer=_l.VIS_NONE):
         self._lib = _l.load()
         self.width, self.height = int(width), int(height)
         self.total = 3 * self.width * self.height
         self.max_batch = int(max_batch)
         cfg = _l.Config(self.width, self.height, int(threshold), self.max_batch, int(device),
-                        int(bool(noise_filter)), int(visualizer), (_l.FLAG_FUSED if fused else 0) | (_l.FLAG_CHAIN if chain else 0))
+                        int(bool(noise_filter)), int(visualizer), 0)
         h = C.c_void_p()
         _l.check(self._lib.mi355_create(C.byref(cfg), C.byref(h)))
         self._h = h
+        # The device-resident entry points are asynchronous on the core's OWN stream, which PyTorch's caching allocator
+        # knows nothing about: a tensor the caller drops right after the call (a temporary, a slice) could be handed to
+        # another torch kernel while the library still reads or writes it.  Every such call therefore keeps its
+        # arguments referenced here until synchronize() (include/mi355diff.h, "Lifetime of the caller's buffers").
+        self._held = []
+        self._own_stream = True
         if k is not None:  # cudaMemcpyToSymbol(dev_k, ...) kernels.cu:394
             k = np.ascontiguousarray(k, dtype=np.float32).reshape(-1)
             assert k.size == 9
@@ -80,8 +86,17 @@ class CUDACore:
     # -- life cycle -------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.mi355_destroy(self._h)
+            self._lib.mi355_destroy(self._h)   # completes the core's streams first
             self._h = None
+        self._held = []
+
+    def _hold(self, *objs):
+        """Keeps the arguments of an asynchronous call alive until the next synchronize()."""
+        if not self._own_stream:
+            return   # a caller's (torch) stream: the allocator orders reuse on that very stream
+        if len(self._held) > 4096:   # a caller that never synchronises: bound the list
+            self.synchronize()
+        self._held.append([o for o in objs if o is not None and not isinstance(o, (int, np.ndarray))])
 
     def __del__(self):
         try:
@@ -103,13 +118,27 @@ class CUDACore:
         """Enqueue on PyTorch's current stream (0 = the default stream), so torch ops, events and
         collectives issued on it are ordered with the core's kernels."""
         import torch
-        _l.check(self._lib.mi355_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        _l.check(self._lib.mi355_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))   # waits for the old stream
+        self._own_stream = False
+        self._held = []
 
     def use_own_stream(self):
         _l.check(self._lib.mi355_use_own_stream(self._h))
+        self._own_stream = True
 
     def synchronize(self):
         _l.check(self._lib.mi355_synchronize(self._h))
+        self._held = []
+
+    def set_option(self, option, value):
+        """lib.OPT_*: the schedule of the own-stream batches (include/mi355diff.h, "Options"); never a result."""
+        _l.check(self._lib.mi355_set_option(self._h, int(option), int(value)))
+        self._held = []   # (the call completed what was queued)
+
+    def get_option(self, option):
+        v = C.c_int(0)
+        _l.check(self._lib.mi355_get_option(self._h, int(option), C.byref(v)))
+        return v.value
 
     # -- reference surface ------------------------------------------------------------------------
     @staticmethod
@@ -176,11 +205,13 @@ class CUDACore:
 
     # -- device-resident hot path -----------------------------------------------------------------
     def diff_stream_batch(self, d_frames, nframes, d_offsets, d_xs, d_diff, capacity, stride=None):
+        self._hold(d_frames, d_offsets, d_xs, d_diff)
         stride = self.total if stride is None else stride
         _l.check(self._lib.mi355_diff_stream_batch(self._h, _ptr(d_frames), stride, nframes,
                                                    _ptr(d_offsets), _ptr(d_xs), _ptr(d_diff), capacity))
 
     def diff_pairs_batch(self, d_cur, d_prev, nframes, d_offsets, d_xs, d_diff, capacity, stride=None):
+        self._hold(d_cur, d_prev, d_offsets, d_xs, d_diff)
         stride = self.total if stride is None else stride
         _l.check(self._lib.mi355_diff_pairs_batch(self._h, _ptr(d_cur), _ptr(d_prev), stride, nframes,
                                                   _ptr(d_offsets), _ptr(d_xs), _ptr(d_diff), capacity))
@@ -188,6 +219,7 @@ class CUDACore:
     # -- the stream either side of the path (wire format, client, row-band merge) -------------------
     def diff_stream_wire_batch(self, d_frames, nframes, d_offsets, d_wire, capacity_bytes, stride=None):
         """threads.cpp:227-229 byte stream of the batch: {u32 n, i32 xs[n], u8 diff[n]} per frame."""
+        self._hold(d_frames, d_offsets, d_wire)
         stride = self.total if stride is None else stride
         _l.check(self._lib.mi355_diff_stream_wire_batch(self._h, _ptr(d_frames), stride, nframes,
                                                         _ptr(d_offsets), _ptr(d_wire), capacity_bytes))
@@ -197,11 +229,13 @@ class CUDACore:
 
     def apply_batch(self, d_offsets, d_xs, d_diff, nframes, d_frames_out=None, stride=None):
         """client/opencv.cpp:64-66 on this core's state, frame by frame."""
+        self._hold(d_offsets, d_xs, d_diff, d_frames_out)
         stride = self.total if stride is None else stride
         _l.check(self._lib.mi355_apply_batch(self._h, _ptr(d_offsets), _ptr(d_xs), _ptr(d_diff), nframes,
                                              _ptr(d_frames_out), stride))
 
     def apply_wire_batch(self, d_wire, counts, nframes, d_frames_out=None, stride=None):
+        self._hold(d_wire, d_frames_out)
         stride = self.total if stride is None else stride
         counts = np.ascontiguousarray(counts, dtype=np.uint32)
         assert counts.size >= nframes
@@ -211,6 +245,7 @@ class CUDACore:
     def merge_parts(self, d_part_offsets, part_base, xs_bias, d_xs_all, d_diff_all, nframes, d_offsets, d_xs,
                     d_diff, capacity):
         """Row-band streams of one video stream -> the stream of the whole frame."""
+        self._hold(d_part_offsets, d_xs_all, d_diff_all, d_offsets, d_xs, d_diff)
         part_base = np.ascontiguousarray(part_base, dtype=np.uint32)
         xs_bias = np.ascontiguousarray(xs_bias, dtype=np.int32)
         assert part_base.size == xs_bias.size
@@ -220,49 +255,61 @@ class CUDACore:
                                              capacity))
 
     def int_diff(self, d_cur, d_prev, d_out, n):
+        self._hold(d_cur, d_prev, d_out)
         _l.check(self._lib.mi355_int_diff(self._h, _ptr(d_cur), _ptr(d_prev), _ptr(d_out), n))
 
     # -- filters ----------------------------------------------------------------------------------
     def gray_avg(self, d_in, d_out):
+        self._hold(d_in, d_out)
         _l.check(self._lib.mi355_gray_avg(self._h, _ptr(d_in), _ptr(d_out)))
 
     def gray_weighted(self, d_in, d_out):
+        self._hold(d_in, d_out)
         _l.check(self._lib.mi355_gray_weighted(self._h, _ptr(d_in), _ptr(d_out)))
 
     def binarize_chain(self, d_gray, d_out, d_hist=None, d_thr=None):
+        self._hold(d_gray, d_out, d_hist, d_thr)
         _l.check(self._lib.mi355_binarize_chain(self._h, _ptr(d_gray), _ptr(d_out), _ptr(d_hist),
                                                 _ptr(d_thr)))
 
     def conv_kxk(self, d_in, d_out, k):
         """The K x K filter of the reference's filter study (noise_filter_benchmark/v2.cu:36-80); k: K*K floats."""
+        self._hold(d_in, d_out)
         k = np.ascontiguousarray(k, dtype=np.float32).reshape(-1)
         K = int(round(k.size ** 0.5))
         assert K * K == k.size
         _l.check(self._lib.mi355_conv_kxk(self._h, _ptr(d_in), _ptr(d_out), k.ctypes.data, K))
 
     def heat_map(self, d_cur, d_prev, d_out):
+        self._hold(d_cur, d_prev, d_out)
         _l.check(self._lib.mi355_heat_map(self._h, _ptr(d_cur), _ptr(d_prev), _ptr(d_out)))
 
     def red_dense(self, d_cur, d_prev, d_out):
+        self._hold(d_cur, d_prev, d_out)
         _l.check(self._lib.mi355_red_dense(self._h, _ptr(d_cur), _ptr(d_prev), _ptr(d_out)))
 
     def red_overlap(self, d_img, d_xs, d_count=None, count=0):
+        self._hold(d_img, d_xs, d_count)
         _l.check(self._lib.mi355_red_overlap(self._h, _ptr(d_img), _ptr(d_xs), _ptr(d_count), count))
 
     def red_stream_batch(self, d_offsets, d_xs, nframes, d_frames, clear=True, stride=None):
         """Red motion maps of a batch from its packed stream (kernels.cu:513-518 per frame)."""
+        self._hold(d_offsets, d_xs, d_frames)
         stride = self.total if stride is None else stride
         _l.check(self._lib.mi355_red_stream_batch(self._h, _ptr(d_offsets), _ptr(d_xs), nframes, _ptr(d_frames),
                                                   stride, int(bool(clear))))
 
     def conv3x3(self, d_in, d_out):
+        self._hold(d_in, d_out)
         _l.check(self._lib.mi355_conv3x3(self._h, _ptr(d_in), _ptr(d_out)))
 
     def median5x5(self, d_in, d_out):
+        self._hold(d_in, d_out)
         _l.check(self._lib.mi355_median5x5(self._h, _ptr(d_in), _ptr(d_out)))
 
     def filter_batch(self, op, d_in, d_out, nframes, d_in2=None, stride=None):
         """Batched per-frame filter (lib.OP_*): one launch per kernel for nframes frames."""
+        self._hold(d_in, d_out, d_in2)
         stride = self.total if stride is None else stride
         _l.check(self._lib.mi355_filter_batch(self._h, int(op), _ptr(d_in), _ptr(d_in2), _ptr(d_out), stride,
                                               nframes))

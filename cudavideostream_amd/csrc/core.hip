@@ -9,7 +9,7 @@
 //                          of every frame), chunk-interleaved over tiles
 //   rec       T*W*64*16    record log: 16 masked diff bytes per lane with two or more flagged bytes
 //   meta      T*W*16       per (frame, tile): code position, record position, flagged bytes, candidates | multi << 16
-//   groff     T*ceil(W/64)*16 (a prefix per range of 16 tiles);  totals (T+1)*4 (+ticket);  offsets (T+1)*4
+//   groff     T*ceil(W/64)*16 (a prefix per range of 16 tiles);  totals T*8 {total, epoch} + the ticket;  offsets (T+1)*4
 //   one_xs N*4, one_diff N exec(): packed output of a single frame before the D2H copies
 //   hist T*256*4, thr T*4 (per frame of a filter batch), k9 9*4, heat LUT 766*3, glyph atlas
 #include <cmath>
@@ -61,23 +61,9 @@ struct mi355_core {
     uint8_t *state = nullptr, *in = nullptr, *aux = nullptr, *vis = nullptr;
     uint4 *rec = nullptr, *meta = nullptr;
     uint32_t *codes = nullptr;
-    uint32_t *groff = nullptr, *totals = nullptr;
+    uint32_t *groff = nullptr, *totals = nullptr;   // totals: T tagged 64-bit words + the scan kernel's ticket (2T + 2 words)
+    uint32_t scan_epoch = 0;      // tag of the last k_scan_groups launch (diff_pack.hip, publish_total)
     uint32_t *offsets = nullptr;  // T+1, used by exec()
-    // one-kernel stream form (diff_fused.hip, opt-in experiment); fused == false: not asked for, or the frame does not fit
-    bool fused = false;
-    uint32_t nwg = 0, fgroups = 0;
-    uint32_t *f_wgsum = nullptr, *f_sync = nullptr, *f_ovf = nullptr;   // f_sync = {status[16], arrive[E], garrive[E*G], gsum[T*G]}; f_ready: a line per workgroup
-    uint32_t *f_ready = nullptr;
-    uint32_t f_tag = 0;            // launch tag of the wgsum and ready words, 1..65535
-    uint4 *f_spill = nullptr;
-    size_t f_sync_words = 0;
-    uint32_t *h_status = nullptr;  // pinned copy of the fused kernel's status word
-    // one-pass pair form (diff_chain.hip)
-    bool chain = false;
-    uint32_t cgroups = 0, c_tag = 0, c_resident = 0;
-    uint64_t *c_desc = nullptr;    // [T][cgroups] then [T] frame totals
-    uint32_t *c_status = nullptr;  // device word
-    uint32_t *h_cstatus = nullptr; // pinned copy
     int32_t *one_xs = nullptr;
     uint8_t *one_diff = nullptr;
     int32_t *hist = nullptr, *thr = nullptr;
@@ -118,23 +104,21 @@ struct mi355_core {
         hipEvent_t packed = nullptr, expanded = nullptr;   // pack kernel done (main) / expansion done (side)
         bool in_use = false;                                // `expanded` has been recorded at least once
     };
-    static constexpr int kMaxSets = 3;
-    LogSet set[kMaxSets];
-    int nsets = 2;                    // MI355_LOGSETS=3: a third set (experiment)
+    static constexpr int kSets = 2;   // (a third set was measured: no gain, profiles/r04ay)
+    LogSet set[kSets];
     int flip = 0;
     hipStream_t side = nullptr;
     hipEvent_t side_done = nullptr;   // == the `expanded` event of the last pipelined batch, or null: nothing pending
-    bool pipeline_ok = true;          // false: MI355_PIPELINE=0, or the second set could not be allocated
+    bool pipeline_ok = true;          // false: MI355_PIPELINE=0 / MI355_OPT_PIPELINE 0, or the second set could not be allocated
+    int pack_blocks_opt = -1;         // MI355_OPT_PACK_BLOCKS (-1: the default, 4 workgroups per CU)
     uint32_t k1_blocks = 0;           // pipelined batches: workgroups of the pack kernel (0 = one tile per wave)
-    bool scan_on_main = false;        // pipelined batches: the index kernel runs on the core's stream, between two pack kernels
     // pipelined batches packed by TWO launches (tiles [0, split) on the core's stream, the rest on `main2`): the two chains
     // of pack kernels drift apart, each one's kernel boundary (L2 write-back, event packets: 21-25 us) falls into the other's
     // kernel.  split_pct = 0: one launch.
-    int split_pct = 50;
-    static constexpr int kMaxParts = 4;
-    int parts = 2;                    // MI355_PARTS=3|4: more launches with equal shares (experiment)
-    hipStream_t main2[kMaxParts - 1] = {};
-    hipEvent_t packed2[kMaxParts - 1][3] = {};
+    // (three or four launches were measured: much slower, profiles/r04ah)
+    int split_pct = 50;               // MI355_OPT_SPLIT_PCT
+    hipStream_t main2 = nullptr;
+    hipEvent_t packed2[kSets] = {};
     // Adaptive overlap: a batch whose expansion is longer than its pack kernel (dense input: a scene change, the synthetic
     // worst cases) loses by running beside the next batch's pack kernel (S0 pairs 0.313 ms one after the other, 0.35
     // overlapped).  The batch total (offsets[nframes]) of every own-stream batch is copied to pinned host memory behind its
@@ -145,18 +129,19 @@ struct mi355_core {
     hipEvent_t tot_ev[kTotSlots] = {};
     int tot_frames[kTotSlots] = {};
     uint32_t tot_next = 0;
-    int dense_pct = 40;               // MI355_DENSE_PCT (0: never switch)
+    int dense_pct = 40;               // MI355_OPT_DENSE_PCT (0: never switch)
     bool dense = false;               // what the latest total that has arrived said
     bool filter_since_batch = false;  // a frame filter ran on this core since the last batch (use_device_filter)
-    bool chain_hint = true;           // MI355_CHAIN_HINT=0 at mi355_create: batches are overlapped regardless
-    hipEvent_t fork[3] = {};          // recorded on the core's stream in front of a batch's first pack launch: the other parts wait for it
+    bool chain_hint = true;           // MI355_OPT_CHAIN_HINT 0: batches are overlapped regardless
+    hipEvent_t fork[kSets] = {};          // recorded on the core's stream in front of a batch's first pack launch: the other parts wait for it
     int parts_pending = -1;           // log set of the last batch whose parts the core's stream has not waited for (-1: none)
 
-    // timing: ring of event sets {before pack, after pack, before scan, after scan, after expand}, harvested lazily
-    // so that timed batches still queue back to back
-    static constexpr int kEvRing = 32, kEvPer = 5;
+    // timing: ring of event sets {before pack, after pack, before scan, after scan, after expand, after the second pack
+    // launch of a split batch}, harvested lazily so that timed batches still queue back to back
+    static constexpr int kEvRing = 32, kEvPer = 6;
     bool timing = false;
     hipEvent_t ev[kEvRing][kEvPer] = {};
+    bool ev_split[kEvRing] = {};
     int ev_head = 0, ev_count = 0;  // oldest pending slot, number pending
     double ms_pack = 0, ms_scan = 0, ms_expand = 0, ms_total = 0;
     int launches = 0;
@@ -196,7 +181,7 @@ int use_device(mi355_core *c, bool join = true, bool parts = true) {
         c->parts_pending = -1;
     }
     if (parts && c->parts_pending >= 0) {
-        for (int p = 0; p + 1 < c->parts; p++) HIP_TRY(hipStreamWaitEvent(c->stream, c->packed2[p][c->parts_pending], 0));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->packed2[c->parts_pending], 0));
         c->parts_pending = -1;
     }
     return MI355_OK;
@@ -207,7 +192,7 @@ int use_device(mi355_core *c, bool join = true, bool parts = true) {
 // filter in front of every diff: BASELINE configs 3 and 4) gains nothing from a batch's expansion running beside the next
 // filter -- both are bound by the memory system -- and loses the pipelined batch's smaller pack grid and stream hops:
 // 4.6 us per frame one after the other, 5.0-5.2 overlapped (config 3, profiles/r04bd).  The next batch therefore runs one
-// kernel after the other on the core's stream (MI355_CHAIN_HINT=0: ignore the hint).
+// kernel after the other on the core's stream (MI355_OPT_CHAIN_HINT 0: ignore the hint).
 int use_device_filter(mi355_core *c) {
     c->filter_since_batch = c->chain_hint;
     return use_device(c, false);
@@ -220,6 +205,11 @@ int harvest_timing(mi355_core *c, int keep = 0) {
         HIP_TRY(hipEventSynchronize(e[4]));
         float a = 0, b = 0, d = 0, t = 0;
         HIP_TRY(hipEventElapsedTime(&a, e[0], e[1]));
+        if (c->ev_split[c->ev_head]) {   // two launches on two streams: the later end counts
+            float a2 = 0;
+            HIP_TRY(hipEventElapsedTime(&a2, e[0], e[5]));
+            a = a2 > a ? a2 : a;
+        }
         HIP_TRY(hipEventElapsedTime(&b, e[2], e[3]));
         HIP_TRY(hipEventElapsedTime(&d, e[3], e[4]));
         HIP_TRY(hipEventElapsedTime(&t, e[0], e[4]));   // the batch's way through the path (batches overlap when pipelined)
@@ -257,237 +247,59 @@ int need_gray1(mi355_core *c) {
     return dev_alloc(c, &c->gray1, c->gray1_stride * (size_t)c->cfg.max_batch);
 }
 
-// The one-kernel stream form needs every workgroup resident at once: decided here, once per core.
-int setup_fused(mi355_core *c) {
-    c->fused = false;
-    const char *env = getenv("MI355_FUSED");
-    if (!(c->cfg.flags & MI355_FLAG_FUSED) && !(env && env[0] == '1')) return MI355_OK;   // opt-in experiment
-#if !MI355_EXPERIMENTS
-    return fail(MI355_ERR_INVALID, "MI355_FLAG_FUSED: this build holds no experiment kernels (make EXPERIMENTS=1)");
-#else
-    if (c->n == 0 || c->n % 16u) return MI355_OK;
-    c->nwg = (c->ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    c->fgroups = fused_groups(c->nwg);
-    const uint32_t cap = fused_capacity(c->device);
-    // workgroups are dealt to the 8 XCDs round-robin: each XCD must hold its share
-    const uint32_t per_xcd = (c->nwg + 7u) / 8u;
-    if (cap == 0 || per_xcd > cap / 8u || c->fgroups > 64u) return MI355_OK;
-    const size_t T = (size_t)c->cfg.max_batch;
-    c->f_sync_words = 16 + (size_t)fused_epochs((int)T) * (1 + c->fgroups) + T * c->fgroups;
-    if (int rc = dev_alloc(c, &c->f_ready, fused_ready_words(c->nwg))) return rc;
-    HIP_TRY(hipMemset(c->f_ready, 0, sizeof(uint32_t) * fused_ready_words(c->nwg)));
-    if (int rc = dev_alloc(c, &c->f_wgsum, T * c->nwg)) return rc;
-    HIP_TRY(hipMemset(c->f_wgsum, 0, sizeof(uint32_t) * T * c->nwg));
-    if (int rc = dev_alloc(c, &c->f_sync, c->f_sync_words)) return rc;
-    if (int rc = dev_alloc(c, &c->f_spill, fused_spill_records(c->ntiles))) return rc;
-    if (int rc = dev_alloc(c, &c->f_ovf, fused_ovf_entries(c->ntiles))) return rc;
-    HIP_TRY(hipHostMalloc((void **)&c->h_status, sizeof(uint32_t), hipHostMallocDefault));
-    *c->h_status = 0;
-    c->fused = true;
-    return MI355_OK;
-#endif
-}
-
-// Experiment, opt-in (MI355_FLAG_CHAIN or MI355_CHAIN=1): the pair form as one chained-scan pass
-// (diff_chain.hip), when the frame bytes are a multiple of 16.
-int setup_chain(mi355_core *c) {
-    c->chain = false;
-    const char *env = getenv("MI355_CHAIN");
-    if (!(c->cfg.flags & MI355_FLAG_CHAIN) && !(env && env[0] == '1')) return MI355_OK;
-#if !MI355_EXPERIMENTS
-    return fail(MI355_ERR_INVALID, "MI355_FLAG_CHAIN: this build holds no experiment kernels (make EXPERIMENTS=1)");
-#else
-    if (c->n == 0 || c->n % 16u) return MI355_OK;
-    c->cgroups = chain_groups(c->ntiles);
-    c->c_resident = chain_capacity(c->device);
-    if (c->c_resident == 0) return MI355_OK;
-    const size_t T = (size_t)c->cfg.max_batch, words = T * c->cgroups + T;
-    if (int rc = dev_alloc(c, &c->c_desc, words)) return rc;
-    HIP_TRY(hipMemset(c->c_desc, 0, words * sizeof(uint64_t)));
-    if (int rc = dev_alloc(c, &c->c_status, 16)) return rc;
-    HIP_TRY(hipMemset(c->c_status, 0, 16 * sizeof(uint32_t)));
-    HIP_TRY(hipHostMalloc((void **)&c->h_cstatus, sizeof(uint32_t), hipHostMallocDefault));
-    *c->h_cstatus = 0;
-    c->chain = true;
-    return MI355_OK;
-#endif
-}
-
-#if MI355_EXPERIMENTS
-int run_chain(mi355_core *c, const void *d_cur, const void *d_prev, size_t stride, int nframes, void *d_offsets,
-              void *d_xs, void *d_diff, size_t capacity) {
-    const size_t T = (size_t)c->cfg.max_batch;
-    if (++c->c_tag > 0xffffu) {   // tags wrap: forget the descriptors of 65535 launches ago
-        c->c_tag = 1;
-        HIP_TRY(hipMemsetAsync(c->c_desc, 0, (T * c->cgroups + T) * sizeof(uint64_t), c->stream));
-    }
-    ChainArgs a{};
-    a.cur = (const uint8_t *)d_cur;
-    a.prev = (const uint8_t *)d_prev;
-    a.stride = stride;
-    a.n = c->n;
-    a.nframes = nframes;
-    a.thr = c->cfg.threshold;
-    a.ntiles = c->ntiles;
-    a.ngroups = c->cgroups;
-    a.tag = c->c_tag;
-    a.desc = c->c_desc;
-    a.fdesc = c->c_desc + T * c->cgroups;
-    a.status = c->c_status;
-    a.offsets = (uint32_t *)d_offsets;
-    a.out_xs = (int32_t *)d_xs;
-    a.out_diff = (uint8_t *)d_diff;
-    a.capacity = capacity;
-    HIP_TRY(launch_diff_chain(a, c->c_resident, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_cstatus, c->c_status, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    return MI355_OK;
-}
-
-int run_fused(mi355_core *c, const void *d_cur, size_t stride, int nframes, void *d_offsets, void *d_xs,
-              void *d_diff, size_t capacity) {
-    FusedArgs f{};
-    f.cur = (const uint8_t *)d_cur;
-    f.state = c->state;
-    f.stride = stride;
-    f.n = c->n;
-    f.nframes = nframes;
-    f.thr = c->cfg.threshold;
-    f.ntiles = c->ntiles;
-    f.nwg = c->nwg;
-    f.ngroups = c->fgroups;
-    f.wgsum = c->f_wgsum;
-    if (++c->f_tag > 0xffffu) {   // tags wrap: forget the words of 65535 launches ago
-        c->f_tag = 1;
-        HIP_TRY(hipMemsetAsync(c->f_wgsum, 0, sizeof(uint32_t) * (size_t)c->cfg.max_batch * c->nwg, c->stream));
-        HIP_TRY(hipMemsetAsync(c->f_ready, 0, sizeof(uint32_t) * fused_ready_words(c->nwg), c->stream));
-    }
-    const size_t E = fused_epochs(nframes);
-    f.tag = c->f_tag;
-    f.status = c->f_sync;
-    f.arrive = c->f_sync + 16;
-    f.garrive = f.arrive + E;
-    f.gsum = f.garrive + E * c->fgroups;
-    f.ready = c->f_ready;
-    f.offsets = (uint32_t *)d_offsets;
-    f.out_xs = (int32_t *)d_xs;
-    f.out_diff = (uint8_t *)d_diff;
-    f.capacity = capacity;
-    f.spill = c->f_spill;
-    f.ovf = c->f_ovf;
-    const size_t words = 16 + E * (1 + c->fgroups) + (size_t)nframes * c->fgroups;
-    HIP_TRY(hipMemsetAsync(c->f_sync, 0, words * sizeof(uint32_t), c->stream));
-    HIP_TRY(launch_diff_fused(f, c->stream));
-    // a bounded wait that expired leaves the outputs undefined: the status word travels to the host with
-    // the stream and is looked at by mi355_synchronize
-    HIP_TRY(hipMemcpyAsync(c->h_status, c->f_sync, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    return MI355_OK;
-}
-#endif
-
 // The second set of logs and the side stream of the pipelined mode, made when it is first used.
 int setup_pipeline(mi355_core *c) {
     if (c->side || !c->pipeline_ok) return MI355_OK;
-    const char *env = getenv("MI355_PIPELINE");
-    if (env && env[0] == '0') { c->pipeline_ok = false; return MI355_OK; }
     // Pipelined batches: the pack kernel on 4 workgroups per CU (16 waves: half of them walk a second tile) instead of
     // one tile per wave (6 per CU).  It is bound by the memory system and does not need its occupancy (profiles/README.md,
     // round 1), while the expansion of the batch before, which shares the chip with it, lives on the wave slots and
     // registers that are left: 0.503-0.507 -> 0.487-0.497 ms per batch on the faster boxes, +-1 % on the slower ones
-    // (profiles/r04p, r04q, r04v).  MI355_K1_BLOCKS=n overrides (0 = one tile per wave).
-    {
+    // (profiles/r04p, r04q, r04v).  MI355_OPT_PACK_BLOCKS overrides (0 = one tile per wave).
+    if (c->pack_blocks_opt >= 0) {
+        c->k1_blocks = (uint32_t)c->pack_blocks_opt;
+    } else {
         hipDeviceProp_t prop{};
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
             c->k1_blocks = 4u * (uint32_t)prop.multiProcessorCount;
     }
-    if (const char *b = getenv("MI355_K1_BLOCKS")) c->k1_blocks = (uint32_t)atoi(b);   // tuning knob (tools/, profiles/)
-    if (const char *b = getenv("MI355_SCAN_MAIN")) c->scan_on_main = b[0] == '1';
-    if (const char *b = getenv("MI355_SPLIT")) c->split_pct = atoi(b);
-    if (c->split_pct < 5 || c->split_pct > 95) c->split_pct = 0;
-    if (const char *b = getenv("MI355_PARTS")) c->parts = atoi(b);
-    if (c->parts < 2 || c->parts > mi355_core::kMaxParts) c->parts = 2;
-    if (const char *b = getenv("MI355_LOGSETS")) c->nsets = atoi(b) == 3 ? 3 : 2;
-    if (const char *b = getenv("MI355_DENSE_PCT")) c->dense_pct = atoi(b);
-    int side_prio = 0;
-    if (const char *b = getenv("MI355_SIDE_PRIO")) side_prio = atoi(b);   // 1: the side stream gets the highest stream priority
     const size_t T = (size_t)c->cfg.max_batch, W = c->ntiles;
-    mi355_core::LogSet &s0 = c->set[0];
+    mi355_core::LogSet &s0 = c->set[0], &s1 = c->set[1];
     s0.rec = c->rec; s0.codes = c->codes; s0.meta = c->meta; s0.groff = c->groff; s0.totals = c->totals;
     bool ok = true;
-    for (int i = 1; i < c->nsets; i++) {
-        mi355_core::LogSet &s1 = c->set[i];
-        ok = ok && hipMalloc((void **)&s1.rec, T * W * 1024) == hipSuccess;
-        ok = ok && hipMalloc((void **)&s1.codes, code_chunks(T) * W * 1024) == hipSuccess;
-        ok = ok && hipMalloc((void **)&s1.meta, T * W * 16) == hipSuccess;
-        ok = ok && hipMalloc((void **)&s1.groff, T * expand_groups(c->ntiles) * 16) == hipSuccess;
-        ok = ok && hipMalloc((void **)&s1.totals, (T + 1) * sizeof(uint32_t)) == hipSuccess;
-        ok = ok && hipMemset(s1.totals, 0, (T + 1) * sizeof(uint32_t)) == hipSuccess;   // the scan kernel's ticket
+    ok = ok && hipMalloc((void **)&s1.rec, T * W * 1024) == hipSuccess;
+    ok = ok && hipMalloc((void **)&s1.codes, code_chunks(T) * W * 1024) == hipSuccess;
+    ok = ok && hipMalloc((void **)&s1.meta, T * W * 16) == hipSuccess;
+    ok = ok && hipMalloc((void **)&s1.groff, T * expand_groups(c->ntiles) * 16) == hipSuccess;
+    ok = ok && hipMalloc((void **)&s1.totals, (2 * T + 2) * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(s1.totals, 0, (2 * T + 2) * sizeof(uint32_t)) == hipSuccess;   // epoch 0 = never written; the ticket
+    ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->main2, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->h_tot, mi355_core::kTotSlots * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+    for (int i = 0; i < mi355_core::kTotSlots && ok; i++) {
+        c->h_tot[i] = 0;
+        ok = hipEventCreateWithFlags(&c->tot_ev[i], hipEventDisableTiming) == hipSuccess;
     }
-    // Experiment (MI355_CU_SPLIT=n, 1..31): the side stream on n CUs of every XCD, the core's stream on the others
-    // (hipExtStreamCreateWithCUMask; mask bit i = CU i / 8 of XCD i % 8): the expansion and the pack kernel then share the
-    // memory system only, not each other's issue slots.
-    int cu_split = 0;
-    if (const char *b = getenv("MI355_CU_SPLIT")) cu_split = atoi(b);
-    if (cu_split > 0 && cu_split < 32) {
-        uint32_t side_mask[8], main_mask[8];
-        for (int w = 0; w < 8; w++) {
-            side_mask[w] = 0; main_mask[w] = 0;
-            for (int bit = 0; bit < 32; bit++) {
-                const int i = w * 32 + bit;
-                if (i < 8 * cu_split) side_mask[w] |= 1u << bit; else main_mask[w] |= 1u << bit;
-            }
-        }
-        hipStream_t m = nullptr;
-        ok = ok && hipExtStreamCreateWithCUMask(&c->side, 8, side_mask) == hipSuccess;
-        ok = ok && hipExtStreamCreateWithCUMask(&m, 8, main_mask) == hipSuccess;
-        if (ok) {   // the core moves to the masked stream (nothing is queued on the old one at this point: first batch call)
-            (void)hipStreamSynchronize(c->own_stream);
-            (void)hipStreamDestroy(c->own_stream);
-            c->own_stream = m;
-            c->stream = m;
-        }
-    } else if (side_prio) {
-        int lo = 0, hi = 0;
-        ok = ok && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
-        ok = ok && hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi) == hipSuccess;
-    } else {
-        ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
-    }
-    if (c->split_pct) {
-        for (int p = 0; p + 1 < c->parts; p++) {
-            ok = ok && hipStreamCreateWithFlags(&c->main2[p], hipStreamNonBlocking) == hipSuccess;
-            for (int i = 0; i < c->nsets && ok; i++) ok = hipEventCreateWithFlags(&c->packed2[p][i], hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
-        }
-        for (int i = 0; i < c->nsets && ok; i++) ok = hipEventCreateWithFlags(&c->fork[i], hipEventDisableTiming | hipEventReleaseToDevice) == hipSuccess;
-    }
-    if (c->dense_pct > 0 && c->dense_pct < 100) {
-        ok = ok && hipHostMalloc((void **)&c->h_tot, mi355_core::kTotSlots * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
-        for (int i = 0; i < mi355_core::kTotSlots && ok; i++) {
-            c->h_tot[i] = 0;
-            ok = hipEventCreateWithFlags(&c->tot_ev[i], hipEventDisableTiming) == hipSuccess;
-        }
-    }
-    for (int i = 0; i < c->nsets && ok; i++) {
+    for (int i = 0; i < mi355_core::kSets && ok; i++) {
         // device-scope release: these events only order kernels of this device against each other.  An event's default
         // is a SYSTEM-scope fence when it is recorded (caches written back and invalidated for the host's benefit),
         // which every batch paid twice on the core's stream between two pack kernels
-        const unsigned flags = hipEventDisableTiming | (getenv("MI355_EVENT_SYSFENCE") ? 0u : hipEventReleaseToDevice);
+        const unsigned flags = hipEventDisableTiming | hipEventReleaseToDevice;
         ok = hipEventCreateWithFlags(&c->set[i].packed, flags) == hipSuccess &&
-             hipEventCreateWithFlags(&c->set[i].expanded, flags) == hipSuccess;
+             hipEventCreateWithFlags(&c->set[i].expanded, flags) == hipSuccess &&
+             hipEventCreateWithFlags(&c->packed2[i], flags) == hipSuccess &&
+             hipEventCreateWithFlags(&c->fork[i], flags) == hipSuccess;
     }
     if (!ok) {   // not an error: the batches then run one after the other, as with a caller's stream
         (void)hipGetLastError();
-        for (int i = 1; i < mi355_core::kMaxSets; i++) {
-            mi355_core::LogSet &s1 = c->set[i];
-            void *ptrs[] = {s1.rec, s1.codes, s1.meta, s1.groff, s1.totals};
-            for (void *p : ptrs) if (p) (void)hipFree(p);
-            s1 = mi355_core::LogSet{};
-        }
+        void *ptrs[] = {s1.rec, s1.codes, s1.meta, s1.groff, s1.totals};
+        for (void *p : ptrs) if (p) (void)hipFree(p);
+        s1.rec = nullptr; s1.meta = nullptr; s1.codes = s1.groff = s1.totals = nullptr;
         if (c->side) { (void)hipStreamDestroy(c->side); c->side = nullptr; }
-        for (auto &m : c->main2) if (m) { (void)hipStreamDestroy(m); m = nullptr; }
+        if (c->main2) { (void)hipStreamDestroy(c->main2); c->main2 = nullptr; }
         c->pipeline_ok = false;
         return MI355_OK;
     }
-    c->workspace += (size_t)(c->nsets - 1) * (T * W * 1024 + code_chunks(T) * W * 1024 + T * W * 16 + T * expand_groups(c->ntiles) * 16 + (T + 1) * 4);
+    c->workspace += T * W * 1024 + code_chunks(T) * W * 1024 + T * W * 16 + T * expand_groups(c->ntiles) * 16 + (2 * T + 2) * 4;
     return MI355_OK;
 }
 
@@ -509,9 +321,6 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     if (nframes > 0 && stride < c->n) return fail(MI355_ERR_INVALID, "stride_bytes < frame bytes");
     if (capacity > 0 && !d_wire && (!d_xs || !d_diff)) return fail(MI355_ERR_INVALID, "null output pointer");
     pipelined = pipelined && c->stream == c->own_stream && c->pipeline_ok && nframes > 0 && c->n > 0;
-#if MI355_EXPERIMENTS
-    pipelined = pipelined && !c->fused && !c->chain;
-#endif
     const bool own = pipelined;   // an own-stream batch (its total is recorded for the next decisions)
     if (c->filter_since_batch) pipelined = false;   // a filter / batch chain: one kernel after the other (use_device_filter)
     c->filter_since_batch = false;
@@ -520,7 +329,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
         if (int rc = setup_pipeline(c)) return rc;
         pipelined = c->pipeline_ok;
     }
-    if (pipelined && c->h_tot) {
+    if (pipelined && c->h_tot && c->dense_pct > 0 && c->dense_pct < 100) {
         // the latest batch total that has arrived: dense input -> this batch runs after the expansion of the one before
         for (uint32_t k = 1; k <= (uint32_t)mi355_core::kTotSlots && k <= c->tot_next; k++) {
             const uint32_t slot = (c->tot_next - k) % mi355_core::kTotSlots;
@@ -553,24 +362,6 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     hipStream_t tail = pipelined ? c->side : c->stream;   // where the index and the expansion run
     if (pipelined && ls.in_use) HIP_TRY(hipStreamWaitEvent(c->stream, ls.expanded, 0));
     if (tev) HIP_TRY(hipEventRecord(tev[0], c->stream));
-#if MI355_EXPERIMENTS
-    if (c->fused && !pair && !d_wire && (((uintptr_t)d_cur | stride) & 15u) == 0) {
-        if (int rc = run_fused(c, d_cur, stride, nframes, d_offsets, d_xs, d_diff, capacity)) return rc;
-        if (tev) {
-            for (int i = 1; i < mi355_core::kEvPer; i++) HIP_TRY(hipEventRecord(tev[i], c->stream));
-            c->ev_count += 1;
-        }
-        return MI355_OK;
-    }
-    if (c->chain && pair && !d_wire && (((uintptr_t)d_cur | (uintptr_t)d_prev | stride) & 15u) == 0) {
-        if (int rc = run_chain(c, d_cur, d_prev, stride, nframes, d_offsets, d_xs, d_diff, capacity)) return rc;
-        if (tev) {
-            for (int i = 1; i < mi355_core::kEvPer; i++) HIP_TRY(hipEventRecord(tev[i], c->stream));
-            c->ev_count += 1;
-        }
-        return MI355_OK;
-    }
-#endif
     PackArgs a{};
     a.cur = (const uint8_t *)d_cur;
     a.prev = (const uint8_t *)d_prev;
@@ -603,64 +394,49 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
         for (int64_t k = k0 - 1; k <= k0 + 1; k++)
             if (k > -T && k < T && (d - k * st < 0 ? k * st - d : d - k * st) < (int64_t)c->n) shared = true;
         pair_once = !shared;
-        static const char *force = getenv("MI355_PAIR_ONCE");   // "0" / "1": A/B runs
-        if (force) pair_once = force[0] == '1';
     }
-    const bool split = pipelined && c->split_pct && c->main2[0] && c->ntiles >= 64;
+    const bool split = pipelined && c->split_pct && c->main2 && c->ntiles >= 64;
     if (split) {
-        // first part on the core's stream, the others on streams of their own (which also have to see the log set free);
-        // each part takes its share of the pipelined grid
-        const uint32_t P = (uint32_t)c->parts;
-        uint32_t begin = 0, blocks_left = c->k1_blocks;
-        // the parts on other streams start behind everything the core's stream holds so far (a filter that is still
-        // writing the frames this batch reads; the upload of the state)
-        HIP_TRY(hipEventRecord(c->fork[c->flip], c->stream));
-        for (uint32_t p = 0; p < P; p++) {
-            const uint32_t share = P == 2 ? (p == 0 ? (uint32_t)c->split_pct : 100u) : (p + 1u) * 100u / P;   // cumulative per cent
-            const uint32_t end = p + 1u == P ? c->ntiles : (uint32_t)((uint64_t)c->ntiles * share / 100u) & ~3u;
-            uint32_t blocks = 0;
-            if (c->k1_blocks) {
-                blocks = p + 1u == P ? blocks_left : (uint32_t)((uint64_t)c->k1_blocks * (end - begin) / c->ntiles);
-                if (blocks == 0) blocks = 1;
-                blocks_left = blocks_left > blocks ? blocks_left - blocks : 1u;
-            }
-            PackArgs ap = a;
-            ap.tile_begin = begin;
-            ap.tile_end = end;
-            hipStream_t sp = p == 0 ? c->stream : c->main2[p - 1];
-            if (p > 0) HIP_TRY(hipStreamWaitEvent(sp, c->fork[c->flip], 0));
-            if (p > 0 && ls.in_use) HIP_TRY(hipStreamWaitEvent(sp, ls.expanded, 0));
-            HIP_TRY(launch_diff_pack(ap, pair, aligned, pair_once, blocks, sp));
-            if (p > 0) {
-                HIP_TRY(hipEventRecord(c->packed2[p - 1][c->flip], sp));
-                HIP_TRY(hipStreamWaitEvent(tail, c->packed2[p - 1][c->flip], 0));
-            }
-            begin = end;
+        // tiles [0, cut) on the core's stream, the rest on a stream of its own (which also has to see the log set free
+        // and everything the core's stream holds so far: a filter that is still writing the frames this batch reads,
+        // the upload of the state); each part takes its share of the pipelined grid
+        const uint32_t cut = (uint32_t)((uint64_t)c->ntiles * (uint32_t)c->split_pct / 100u) & ~3u;
+        uint32_t blocks0 = 0, blocks1 = 0;
+        if (c->k1_blocks) {
+            blocks0 = (uint32_t)((uint64_t)c->k1_blocks * cut / c->ntiles);
+            if (blocks0 == 0) blocks0 = 1;
+            blocks1 = c->k1_blocks > blocks0 ? c->k1_blocks - blocks0 : 1u;
         }
+        HIP_TRY(hipEventRecord(c->fork[c->flip], c->stream));
+        PackArgs a0 = a, a1 = a;
+        a0.tile_end = cut;
+        a1.tile_begin = cut;
+        HIP_TRY(launch_diff_pack(a0, pair, aligned, pair_once, blocks0, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->main2, c->fork[c->flip], 0));
+        if (ls.in_use) HIP_TRY(hipStreamWaitEvent(c->main2, ls.expanded, 0));
+        HIP_TRY(launch_diff_pack(a1, pair, aligned, pair_once, blocks1, c->main2));
+        HIP_TRY(hipEventRecord(c->packed2[c->flip], c->main2));
+        HIP_TRY(hipStreamWaitEvent(tail, c->packed2[c->flip], 0));
+        if (tev) HIP_TRY(hipEventRecord(tev[5], c->main2));   // the pack "kernel" of a split batch ends when BOTH parts have
         c->parts_pending = c->flip;
     } else {
         HIP_TRY(launch_diff_pack(a, pair, aligned, pair_once, pipelined ? c->k1_blocks : 0u, c->stream));
     }
-    if (tev) HIP_TRY(hipEventRecord(tev[1], c->stream));
-    // The index kernel is short (12 us alone) and gates the expansion: behind the next batch's pack kernel on the side
-    // stream it waits for wave slots and for memory round trips that take ten times as long there; on the core's
-    // stream it runs before the next pack kernel starts.
-    const bool scan_main = pipelined && c->scan_on_main;
-    hipStream_t ss = scan_main ? c->stream : tail;
-    if (scan_main && split)   // the index reads every part's meta words
-        for (int p = 0; p + 1 < c->parts; p++) HIP_TRY(hipStreamWaitEvent(c->stream, c->packed2[p][c->flip], 0));
-    if (pipelined && !scan_main) {
+    if (tev) {
+        HIP_TRY(hipEventRecord(tev[1], c->stream));
+        c->ev_split[(c->ev_head + c->ev_count) % mi355_core::kEvRing] = split;
+    }
+    // The index kernel is short (12 us alone) and gates the expansion; it runs in front of it on the side stream (on the
+    // core's stream, between two pack kernels, was measured: worse, profiles/r04a).
+    if (pipelined) {
         HIP_TRY(hipEventRecord(ls.packed, c->stream));
         HIP_TRY(hipStreamWaitEvent(tail, ls.packed, 0));
     }
-    if (tev) HIP_TRY(hipEventRecord(tev[2], ss));
-    HIP_TRY(launch_scan(ls.meta, ls.groff, ls.totals, c->ntiles, nframes, (uint32_t *)d_offsets,
-                        ls.totals + c->cfg.max_batch, ss));
-    if (tev) HIP_TRY(hipEventRecord(tev[3], ss));
-    if (scan_main) {
-        HIP_TRY(hipEventRecord(ls.packed, c->stream));
-        HIP_TRY(hipStreamWaitEvent(tail, ls.packed, 0));
-    }
+    if (tev) HIP_TRY(hipEventRecord(tev[2], tail));
+    if (++c->scan_epoch == 0) c->scan_epoch = 1;
+    HIP_TRY(launch_scan(ls.meta, ls.groff, (uint64_t *)ls.totals, c->ntiles, nframes, (uint32_t *)d_offsets,
+                        ls.totals + 2 * (size_t)c->cfg.max_batch, c->scan_epoch, tail));
+    if (tev) HIP_TRY(hipEventRecord(tev[3], tail));
     ExpandArgs g{};
     g.rec = ls.rec;
     g.codes = ls.codes;
@@ -679,7 +455,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
         HIP_TRY(hipEventRecord(tev[4], tail));
         c->ev_count += 1;
     }
-    if (own && c->h_tot && c->pipeline_ok) {
+    if (own && c->h_tot && c->pipeline_ok && c->dense_pct > 0 && c->dense_pct < 100) {
         const uint32_t slot = c->tot_next % mi355_core::kTotSlots;
         HIP_TRY(hipMemcpyAsync(&c->h_tot[slot], (const uint32_t *)d_offsets + nframes, sizeof(uint32_t), hipMemcpyDeviceToHost, tail));
         HIP_TRY(hipEventRecord(c->tot_ev[slot], tail));
@@ -690,7 +466,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
         HIP_TRY(hipEventRecord(ls.expanded, tail));
         ls.in_use = true;
         c->side_done = ls.expanded;
-        c->flip = (c->flip + 1) % c->nsets;
+        c->flip ^= 1;
     }
     return MI355_OK;
 }
@@ -709,12 +485,9 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (cfg->width < 0 || cfg->height < 0) return fail(MI355_ERR_INVALID, "negative frame size");
     // |df| of two bytes is at most 255: a threshold of 255 flags nothing; larger or negative values are refused
     if (cfg->threshold < 0 || cfg->threshold > 255) return fail(MI355_ERR_INVALID, "threshold outside 0..255");
-#if MI355_EXPERIMENTS
-    if (cfg->threshold > 127 && (cfg->flags & (MI355_FLAG_FUSED | MI355_FLAG_CHAIN)))
-        return fail(MI355_ERR_INVALID, "the experiment kernels take thresholds 0..127");
-#endif
     if (cfg->max_batch < 1) return fail(MI355_ERR_INVALID, "max_batch < 1");
     if (cfg->visualizer < 0 || cfg->visualizer > 5) return fail(MI355_ERR_INVALID, "unknown visualizer");
+    if (cfg->flags != 0) return fail(MI355_ERR_INVALID, "flags: no flag is defined in this version of the library (must be 0)");
     const uint64_t n64 = 3ull * (uint64_t)cfg->width * (uint64_t)cfg->height;
     if (n64 >= (1ull << 31)) return fail(MI355_ERR_INVALID, "frame larger than 2 GiB");
     // byte indices are int32 and batch offsets uint32 (the reference's h_xs / h_pos types)
@@ -735,7 +508,8 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     mi355_core *c = new (std::nothrow) mi355_core;
     if (!c) return fail(MI355_ERR_INVALID, "out of host memory");
     c->cfg = *cfg;
-    if (const char *v = getenv("MI355_CHAIN_HINT")) c->chain_hint = v[0] != '0';
+    // the ONE environment variable the library reads (include/mi355diff.h, "Options")
+    if (const char *v = getenv("MI355_PIPELINE")) c->pipeline_ok = v[0] != '0';
     if (cfg->device >= 0) c->device = cfg->device;
     else if ((e = hipGetDevice(&c->device)) != hipSuccess) { delete c; return fail(MI355_ERR_HIP, "hipGetDevice", e); }
     if (c->device >= ndev) { delete c; return fail(MI355_ERR_INVALID, "device ordinal out of range"); }
@@ -747,7 +521,7 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     int rc = use_device(c);
     if (!rc) { e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipStreamCreate", e); }
     c->stream = c->own_stream;
-    for (int i = 0; i < mi355_core::kEvRing * mi355_core::kEvPer && !rc; i++) { e = hipEventCreateWithFlags(&c->ev[i / mi355_core::kEvPer][i % mi355_core::kEvPer], getenv("MI355_EVENT_SYSFENCE") ? hipEventDefault : hipEventDisableSystemFence); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipEventCreate", e); }   // timing events: no system-scope fence (hip_runtime_api.h: "can improve the accuracy of timing measurements by avoiding the cost of cache writeback and invalidation")
+    for (int i = 0; i < mi355_core::kEvRing * mi355_core::kEvPer && !rc; i++) { e = hipEventCreateWithFlags(&c->ev[i / mi355_core::kEvPer][i % mi355_core::kEvPer], hipEventDisableSystemFence); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipEventCreate", e); }   // timing events: no system-scope fence (hip_runtime_api.h: "can improve the accuracy of timing measurements by avoiding the cost of cache writeback and invalidation")
     if (!rc && (e = init_gray_table()) != hipSuccess) rc = fail(MI355_ERR_HIP, "init_gray_table", e);
     if (!rc) rc = dev_alloc(c, &c->state, N + 16);
     if (!rc) rc = dev_alloc(c, &c->in, N + 16);
@@ -757,11 +531,9 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (!rc) rc = dev_alloc(c, &c->codes, code_chunks(T) * W * 256);
     if (!rc) rc = dev_alloc(c, &c->meta, T * W);
     if (!rc) rc = dev_alloc(c, &c->groff, T * expand_groups(c->ntiles) * 4);   // one prefix per range of 16 tiles
-    if (!rc) rc = dev_alloc(c, &c->totals, T + 1);   // + the scan kernel's ticket counter
-    if (!rc) { e = hipMemset(c->totals, 0, (T + 1) * sizeof(uint32_t)); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipMemset", e); }
+    if (!rc) rc = dev_alloc(c, &c->totals, 2 * T + 2);   // T x {total, epoch} + the scan kernel's ticket counter
+    if (!rc) { e = hipMemset(c->totals, 0, (2 * T + 2) * sizeof(uint32_t)); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipMemset", e); }
     if (!rc) rc = dev_alloc(c, &c->offsets, T + 1);
-    if (!rc) rc = setup_fused(c);
-    if (!rc) rc = setup_chain(c);
     if (!rc) rc = dev_alloc(c, &c->one_xs, N + 4);
     if (!rc) rc = dev_alloc(c, &c->one_diff, N + 16);
     if (!rc) rc = dev_alloc(c, &c->hist, 256 * T);
@@ -788,28 +560,24 @@ void mi355_destroy(mi355_core *c) {
     if (c->side) (void)hipStreamSynchronize(c->side);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     {
-        for (int i = 1; i < mi355_core::kMaxSets; i++) {
-            mi355_core::LogSet &s1 = c->set[i];
-            void *more[] = {s1.rec, s1.codes, s1.meta, s1.groff, s1.totals};
-            for (void *p : more) if (p) (void)hipFree(p);
-        }
+        mi355_core::LogSet &s1 = c->set[1];
+        void *more[] = {s1.rec, s1.codes, s1.meta, s1.groff, s1.totals};
+        for (void *p : more) if (p) (void)hipFree(p);
         for (auto &ls : c->set) {
             if (ls.packed) (void)hipEventDestroy(ls.packed);
             if (ls.expanded) (void)hipEventDestroy(ls.expanded);
         }
         if (c->side) (void)hipStreamDestroy(c->side);
-        for (auto &m : c->main2) if (m) { (void)hipStreamSynchronize(m); (void)hipStreamDestroy(m); }
-        for (auto &pe : c->packed2) for (auto &e : pe) if (e) (void)hipEventDestroy(e);
+        if (c->main2) { (void)hipStreamSynchronize(c->main2); (void)hipStreamDestroy(c->main2); }
+        for (auto &e : c->packed2) if (e) (void)hipEventDestroy(e);
         for (auto &e : c->fork) if (e) (void)hipEventDestroy(e);
         for (auto &e : c->tot_ev) if (e) (void)hipEventDestroy(e);
         if (c->h_tot) (void)hipHostFree(c->h_tot);
     }
     void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->codes, c->meta, c->groff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
-                    c->lut, c->glyphs, c->kxk, c->gray1, c->red_bounds, c->f_wgsum, c->f_sync, c->f_spill, c->f_ovf, c->f_ready, c->c_desc, c->c_status};
+                    c->lut, c->glyphs, c->kxk, c->gray1, c->red_bounds};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_count) (void)hipHostFree(c->h_count);
-    if (c->h_status) (void)hipHostFree(c->h_status);
-    if (c->h_cstatus) (void)hipHostFree(c->h_cstatus);
     for (auto &slot : c->ev) for (auto &ev : slot) if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -842,20 +610,60 @@ int mi355_synchronize(mi355_core *c) {
     if (!c) return fail(MI355_ERR_INVALID, "null core");
     if (int rc = use_device(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->h_cstatus && *c->h_cstatus) {
-        *c->h_cstatus = 0;
-        (void)hipMemsetAsync(c->c_status, 0, sizeof(uint32_t), c->stream);
-        c->chain = false;   // the log path waits for nothing
-        return fail(MI355_ERR_STATE, "chained pair kernel: a block waited too long for its predecessors; the batch's "
-                                     "output is undefined, the core now uses the log path");
-    }
-    if (c->h_status && *c->h_status) {
-        *c->h_status = 0;
-        c->fused = false;   // the log path needs no co-residency
-        return fail(MI355_ERR_STATE, "fused diff kernel: a workgroup waited too long for the others (GPU shared?); "
-                                     "the batch's output and the state are undefined, the core now uses the log path");
-    }
     return MI355_OK;
+}
+
+// Options: the schedule of the own-stream batches, never a result.  Changing one first completes what is queued.
+int mi355_set_option(mi355_core *c, int option, int value) {
+    if (!c) return fail(MI355_ERR_INVALID, "null core");
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    switch (option) {
+        case MI355_OPT_PIPELINE:
+            if (value != 0 && value != 1) return fail(MI355_ERR_INVALID, "MI355_OPT_PIPELINE: 0 or 1");
+            // (a core whose second log set could not be allocated stays sequential: setup_pipeline says so by itself)
+            c->pipeline_ok = value == 1;
+            return MI355_OK;
+        case MI355_OPT_SPLIT_PCT:
+            if (value != 0 && (value < 5 || value > 95)) return fail(MI355_ERR_INVALID, "MI355_OPT_SPLIT_PCT: 0 or 5..95");
+            c->split_pct = value;
+            return MI355_OK;
+        case MI355_OPT_DENSE_PCT:
+            if (value < 0 || value > 100) return fail(MI355_ERR_INVALID, "MI355_OPT_DENSE_PCT: 0..100");
+            c->dense_pct = value;
+            c->dense = false;
+            return MI355_OK;
+        case MI355_OPT_CHAIN_HINT:
+            if (value != 0 && value != 1) return fail(MI355_ERR_INVALID, "MI355_OPT_CHAIN_HINT: 0 or 1");
+            c->chain_hint = value == 1;
+            c->filter_since_batch = false;
+            return MI355_OK;
+        case MI355_OPT_PACK_BLOCKS:
+            if (value < -1 || value > (1 << 20)) return fail(MI355_ERR_INVALID, "MI355_OPT_PACK_BLOCKS: -1 (default), 0 (one tile per wave) or a workgroup count");
+            c->pack_blocks_opt = value;
+            if (c->side) {   // the pipelined mode is already set up: takes effect with the next batch
+                if (value >= 0) c->k1_blocks = (uint32_t)value;
+                else {
+                    hipDeviceProp_t prop{};
+                    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+                    c->k1_blocks = 4u * (uint32_t)prop.multiProcessorCount;
+                }
+            }
+            return MI355_OK;
+        default: return fail(MI355_ERR_INVALID, "unknown option");
+    }
+}
+
+int mi355_get_option(mi355_core *c, int option, int *value) {
+    if (!c || !value) return fail(MI355_ERR_INVALID, "null argument");
+    switch (option) {
+        case MI355_OPT_PIPELINE: *value = c->pipeline_ok ? 1 : 0; return MI355_OK;
+        case MI355_OPT_SPLIT_PCT: *value = c->split_pct; return MI355_OK;
+        case MI355_OPT_DENSE_PCT: *value = c->dense_pct; return MI355_OK;
+        case MI355_OPT_CHAIN_HINT: *value = c->chain_hint ? 1 : 0; return MI355_OK;
+        case MI355_OPT_PACK_BLOCKS: *value = c->pack_blocks_opt; return MI355_OK;
+        default: return fail(MI355_ERR_INVALID, "unknown option");
+    }
 }
 
 int mi355_set_state(mi355_core *c, const uint8_t *host_frame) {

@@ -63,6 +63,9 @@ using namespace mi355;
 extern "C" int mi355_probe_hbm_read(mi355_core *c, size_t megabytes, double *gbps) {
     if (!c || !gbps) return set_error(MI355_ERR_INVALID, "null argument");
     if (megabytes < 64 || megabytes > 16384) return set_error(MI355_ERR_INVALID, "megabytes outside [64, 16384]");
+    // the probe's buffers must live on the core's device, whatever device the calling thread used last (a process that
+    // holds cores on several GPUs: a group's members)
+    if (hipSetDevice(core_device(c)) != hipSuccess) return set_error(MI355_ERR_HIP, "hipSetDevice");
     hipStream_t s = core_stream(c);
     const size_t bytes = megabytes << 20;
     u32x4 *d = nullptr;
@@ -75,10 +78,14 @@ extern "C" int mi355_probe_hbm_read(mi355_core *c, size_t megabytes, double *gbp
     if (e == hipSuccess) e = hipEventCreate(&e1);
     hipDeviceProp_t prop{};
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, core_device(c));
+    if (e == hipSuccess && prop.multiProcessorCount <= 0) e = hipErrorInvalidDevice;
     float best = 1e30f;
     for (int rep = 0; rep < 4 && e == hipSuccess; rep++) {   // the first pass warms up; the best of the rest counts
         e = hipEventRecord(e0, s);
-        hipLaunchKernelGGL(k_hbm_read_probe, dim3(prop.multiProcessorCount * 8), dim3(256), 0, s, d, bytes / 16, sink);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_hbm_read_probe, dim3(prop.multiProcessorCount * 8), dim3(256), 0, s, d, bytes / 16, sink);
+            e = hipGetLastError();
+        }
         if (e == hipSuccess) e = hipEventRecord(e1, s);
         if (e == hipSuccess) e = hipEventSynchronize(e1);
         float ms = 0;
@@ -97,9 +104,11 @@ extern "C" int mi355_probe_hbm_read(mi355_core *c, size_t megabytes, double *gbp
 extern "C" int mi355_probe_clock(mi355_core *c, int milliseconds, double *shader_mhz) {
     if (!c || !shader_mhz) return set_error(MI355_ERR_INVALID, "null argument");
     if (milliseconds < 1 || milliseconds > 2000) return set_error(MI355_ERR_INVALID, "milliseconds outside [1, 2000]");
+    if (hipSetDevice(core_device(c)) != hipSuccess) return set_error(MI355_ERR_HIP, "hipSetDevice");   // see mi355_probe_hbm_read
     hipStream_t s = core_stream(c);
     hipDeviceProp_t prop{};
-    if (hipGetDeviceProperties(&prop, core_device(c)) != hipSuccess) return set_error(MI355_ERR_HIP, "hipGetDeviceProperties");
+    if (hipGetDeviceProperties(&prop, core_device(c)) != hipSuccess || prop.multiProcessorCount <= 0)
+        return set_error(MI355_ERR_HIP, "hipGetDeviceProperties");
     const int blocks = prop.multiProcessorCount * 4;   // 4 waves per SIMD
     const size_t waves = (size_t)blocks * 4;
     uint64_t *d = nullptr;

@@ -27,7 +27,8 @@
 //   k_expand    : one wave per (frame, 16 tiles): turns codes and records into the caller's packed,
 //                 frame-major, ascending (xs, diff) arrays -- or the socket's byte stream -- through an
 //                 LDS stage and coalesced stores.
-// No spin waits; the only inter-workgroup communication is the completion ticket of k_scan_groups;
+// The only inter-workgroup communication is the completion ticket of k_scan_groups and the tagged frame totals its last
+// workgroup collects (publish_total);
 // results are independent of dispatch order.
 #include <cstdio>
 #include <vector>
@@ -36,39 +37,16 @@
 
 namespace mi355 {
 
-// Ablation builds (tools/ab_build.sh, never shipped): 1 = no log stores, 2 = also no meta stores,
-// 3 = loads + state fold only (memory floor of the stream loop).  0 = the product.
-#ifndef MI355_ABLATE
-#define MI355_ABLATE 0
-#endif
-
-#ifndef MI355_K1STNT   // timing builds: 1 = code stores, 2 = record stores, 4 = meta stores of the pack kernel non-temporal
-#define MI355_K1STNT 0
-#endif
-#ifndef MI355_K1_LDAUX   // cache policy bits of the once-read frame loads: 1 = sc0, 2 = nt, 16 = sc1 (timing builds try the others)
-#define MI355_K1_LDAUX 2
-#endif
-#ifndef MI355_K1_PREFETCH
-#define MI355_K1_PREFETCH 4
-#endif
-#ifndef MI355_K1PRIO
-#define MI355_K1PRIO 0
-#endif
-// Dense tiles (every lane of a (frame, tile) with two or more flagged bytes) append records only, no codes: a fifth less
-// log for the synthetic worst cases (refrand pairs, P = N); the expander rebuilds the maps from the records (record_map16).
-#ifndef MI355_RECORD_ONLY
-#define MI355_RECORD_ONLY 1
-#endif
-#ifndef MI355_K1_PAD     // timing builds: this many extra vector instructions per frame and tile (what does an instruction cost?)
-#define MI355_K1_PAD 0
-#endif
+// Laboratory builds (tools/ab_build.sh: -DMI355_LAB=1 -DMI355_ABLATE=n ..., never shipped) take parts of the kernels
+// out to price them; the shipped library has kAblate == kXAblate == kPad == 0 (lab.h) and none of that code.
+constexpr int kStreamPrefetch = 4;   // frames per register group of the stream kernel
 // Frames per register group (two groups per wave).  Stream mode: 4 (8 x 1 KiB in flight per wave, 58 VGPRs).  Pair
 // mode holds two operands per frame: with 4 it needed 89 VGPRs = 5 waves per SIMD, and the 6076 waves of a 1080p frame
 // no longer fitted the chip at once (5120 places): a sixth of them ran as a second generation, alone.  With 2 the
 // pair kernel fits 6 waves per SIMD like the stream kernel (the depth of the prefetch was measured not to matter).
 template <bool PAIR>
-struct PrefetchOf { static constexpr int value = PAIR ? (MI355_K1_PREFETCH > 2 ? 2 : MI355_K1_PREFETCH) : MI355_K1_PREFETCH; };
-static_assert(MI355_K1_PREFETCH % 2 == 0, "frames are processed in pairs");
+struct PrefetchOf { static constexpr int value = PAIR ? 2 : kStreamPrefetch; };
+static_assert(kStreamPrefetch % 2 == 0, "frames are processed in pairs");
 
 // ---- the log (round 3) ------------------------------------------------------------------------------
 // What k_diff_pack leaves for k_expand, per (frame, tile):
@@ -108,9 +86,7 @@ __device__ __forceinline__ void compare_step(const uint4 c, uint4 &s, ThrConst t
     uint32_t fh[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-#if MI355_ABLATE == 3
-        sw[k] ^= cw[k]; dm[k] = 0; fh[k] = 0;
-#else
+        if (kAblate == 3) { sw[k] ^= cw[k]; dm[k] = 0; fh[k] = 0; continue; }   // lab: loads + a fold of the state only
         uint32_t x;
         fh[k] = dword_flags<HIGH>(cw[k], sw[k], tc, x);
         // 0xFF in every flagged byte: a v_perm selector byte of 0x80 yields the constant 0xFF, one of 0x00
@@ -120,15 +96,14 @@ __device__ __forceinline__ void compare_step(const uint4 c, uint4 &s, ThrConst t
         // negative feedback (kernels.cu:316-331): flagged bytes take the current value, the others
         // keep the previous one -> the state is the frame the client reconstructs
         sw[k] = bitop3<(TA & TC) | (TB & ~TC)>(cw[k], sw[k], mask);
-#endif
     }
     s = make_uint4(sw[0], sw[1], sw[2], sw[3]);
-#if MI355_K1_PAD
-    { uint32_t pad = cw[0];
+    if (kPad > 0) {   // lab: what does an instruction cost?
+        uint32_t pad = cw[0];
 #pragma unroll
-      for (int i = 0; i < MI355_K1_PAD; i++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(pad) : "v"(cw[1]));
-      asm volatile("" :: "v"(pad)); }
-#endif
+        for (int i = 0; i < kPad; i++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(pad) : "v"(cw[1]));
+        asm volatile("" :: "v"(pad));
+    }
     // flags are 0x80 per flagged byte: two v_dot4 chains weigh them into 128 * (map of 8 bytes)
     const uint32_t lo = __builtin_amdgcn_udot4(fh[1], tc.w1, __builtin_amdgcn_udot4(fh[0], tc.w0, 0u, false), false);
     const uint32_t hi = __builtin_amdgcn_udot4(fh[3], tc.w1, __builtin_amdgcn_udot4(fh[2], tc.w0, 0u, false), false);
@@ -158,30 +133,28 @@ __device__ __forceinline__ uint32_t emit_step(const uint32_t (&dm)[4], uint32_t 
     if (nc == 0u) return 0u;   // wave-uniform: a still tile appends nothing (and issues no store)
     if (nm > lp.roomM) { lp.ptrM += lp.roomM * 16u + jump; lp.roomM = 64u; }
     pm = lp.ptrM;
-#if MI355_RECORD_ONLY
     if (nm == 64u) {   // wave-uniform: a DENSE tile (all 64 lanes carry two or more flagged bytes) appends records only: a
                        // lane's record is record `lane`, and its map is the record's non-zero bytes (|df| > T >= 0 is never 0)
-#if MI355_ABLATE == 0
         const u32x4 v = {dm[0], dm[1], dm[2], dm[3]};
-        __builtin_amdgcn_raw_buffer_store_b128(v, lg.recs, pm + rankM * 16u, 0, (MI355_K1STNT & 2) ? 2 : 0);
-#endif
+        if (kAblate == 0) __builtin_amdgcn_raw_buffer_store_b128(v, lg.recs, pm + rankM * 16u, 0, 0);
         lp.ptrM += 64u * 16u;
         lp.roomM -= 64u;
         return 64u | (64u << 16);
     }
-#endif
     if (nc > lp.roomC) { lp.ptrC += lp.roomC * 4u + jump; lp.roomC = 256u; }
     pc = lp.ptrC;
     // a lane with one flagged byte: the byte sum of its masked differences IS that byte
     const uint32_t one = __builtin_amdgcn_sad_u8((dm[0] | dm[1]) | (dm[2] | dm[3]), 0u, 0u);
     const uint32_t code = m16 | ((multi ? rankM : one) << 16) | lane24;
-#if MI355_ABLATE == 0
-    __builtin_amdgcn_raw_buffer_store_b32(code, lg.codes, cand ? pc + rankC * 4u : kOOB, 0, (MI355_K1STNT & 1) ? 2 : 0);
-    const u32x4 v = {dm[0], dm[1], dm[2], dm[3]};
-    __builtin_amdgcn_raw_buffer_store_b128(v, lg.recs, multi ? pm + rankM * 16u : kOOB, 0, (MI355_K1STNT & 2) ? 2 : 0);
-#else
-    asm volatile("" ::"v"(dm[0]), "v"(dm[1]), "v"(dm[2]), "v"(dm[3]), "v"(rankC), "v"(rankM), "v"(code));
-#endif
+    if (kAblate == 0) {
+        // plain (write-back) stores: the L2 is what merges a tile's 80-byte appends into whole lines (non-temporal log
+        // stores were measured 2-15 % slower, profiles/README.md r04)
+        __builtin_amdgcn_raw_buffer_store_b32(code, lg.codes, cand ? pc + rankC * 4u : kOOB, 0, 0);
+        const u32x4 v = {dm[0], dm[1], dm[2], dm[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(v, lg.recs, multi ? pm + rankM * 16u : kOOB, 0, 0);
+    } else {
+        asm volatile("" ::"v"(dm[0]), "v"(dm[1]), "v"(dm[2]), "v"(dm[3]), "v"(rankC), "v"(rankM), "v"(code));
+    }
     lp.ptrC += nc * 4u;
     lp.roomC -= nc;
     lp.ptrM += nm * 16u;
@@ -211,10 +184,10 @@ struct Group {
     __device__ __forceinline__ void load_desc(__amdgpu_buffer_rsrc_t cur, __amdgpu_buffer_rsrc_t prev, const uint32_t (&voff)[kPrefetch]) {
 #pragma unroll
         for (int d = 0; d < kPrefetch; d++) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(cur, voff[d], 0, (ONCE && MI355_NT_LOADS) ? MI355_K1_LDAUX : 0);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(cur, voff[d], 0, ONCE ? 2 : 0);
             c[d] = make_uint4(v.x, v.y, v.z, v.w);
             if (PAIR) {
-                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(prev, voff[d], 0, (ONCE && MI355_NT_LOADS) ? 2 : 0);
+                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(prev, voff[d], 0, ONCE ? 2 : 0);
                 p[d] = make_uint4(w.x, w.y, w.z, w.w);
             }
         }
@@ -276,28 +249,19 @@ __device__ __forceinline__ void pack_group(const PackArgs &a, const Group<PAIR, 
         write_lane(meta.z, tot >> 16, d + 1);
         write_lane(meta.w, c1, d + 1);
     }
-#if MI355_ABLATE != 2 && MI355_ABLATE != 3
-    const uint32_t moff = (__umul24((uint32_t)t0 + (uint32_t)lane, a.ntiles) + tile) * 16u;
-    const u32x4 mv = {meta.x, meta.y, meta.z, meta.w};
-    __builtin_amdgcn_raw_buffer_store_b128(mv, lg.meta, (lane < kPrefetch && t0 + lane < a.nframes) ? moff : kOOB, 0, (MI355_K1STNT & 4) ? 2 : 0);
-#endif
+    if (kAblate < 2) {
+        const uint32_t moff = (__umul24((uint32_t)t0 + (uint32_t)lane, a.ntiles) + tile) * 16u;
+        const u32x4 mv = {meta.x, meta.y, meta.z, meta.w};
+        __builtin_amdgcn_raw_buffer_store_b128(mv, lg.meta, (lane < kPrefetch && t0 + lane < a.nframes) ? moff : kOOB, 0, 0);
+    }
 }
 
 template <bool PAIR, bool FAST, bool HIGH, bool ONCE>
 __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint32_t byte_off,
                                           int valid, int lane) {
     const int T = a.nframes;
-#ifndef MI355_K1_VCONST
-#define MI355_K1_VCONST 0   // measured: 4 % SLOWER with the constants in vector registers (profiles/r04o): the kernel is not bound by its issue rate
-#endif
-#ifndef MI355_K1_DESC
-#define MI355_K1_DESC 1
-#endif
-#if MI355_K1_VCONST
-    const ThrConst tc = vgpr_consts(make_thr((uint32_t)a.thr));   // in vector registers: see vgpr_const
-#else
+    // the compare constants stay in scalar registers: in vector registers the kernel was 4 % slower (profiles/r04o)
     const ThrConst tc = make_thr((uint32_t)a.thr);
-#endif
     const LogOut lg{make_rsrc(a.codes, a.codes_bytes), make_rsrc(a.rec, a.rec_bytes), make_rsrc(a.meta, a.meta_bytes)};
 
     uint4 st = make_uint4(0, 0, 0, 0);
@@ -309,7 +273,6 @@ __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint
     LogPos lp{tile * 1024u, 256u, tile * 1024u, 64u};   // codes / records this tile has appended to its logs so far
     constexpr int kPrefetch = PrefetchOf<PAIR>::value;
     const size_t gstep = (size_t)kPrefetch * a.stride;
-#if MI355_K1_DESC
     if (FAST) {
         uint32_t voff[kPrefetch];
 #pragma unroll
@@ -336,7 +299,6 @@ __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint
         if (!PAIR) *reinterpret_cast<uint4 *>(a.state + byte_off) = st;
         return;
     }
-#endif
     const uint8_t *cur_last = a.cur + (size_t)(T - 1) * a.stride, *prev_last = PAIR ? a.prev + (size_t)(T - 1) * a.stride : nullptr;
     const uint8_t *cp = a.cur, *pp = a.prev;   // frame t0 + kPrefetch, the next group to request
     ga.load(a, byte_off, 0, valid, cp, pp, cur_last, prev_last);
@@ -361,23 +323,13 @@ __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint
 
 template <bool PAIR, bool ALIGNED, bool HIGH, bool ONCE = !PAIR>
 __global__ __launch_bounds__(256) void k_diff_pack(const PackArgs a) {
-#if MI355_K1PRIO
-    __builtin_amdgcn_s_setprio(MI355_K1PRIO);
-#endif
     const int lane = threadIdx.x & 63;
     // one tile per wave when the grid covers the frame (the default); a smaller grid walks the tiles with its stride
     // (pipelined batches leave wave slots to the expansion of the batch before, core.hip)
     // The wave's number is the same in all its lanes, but the compiler cannot know that of threadIdx.x >> 6: without the
     // readfirstlane everything derived from the tile -- the log positions above all -- lived in VECTOR registers and was
-    // updated with v_cndmask / v_add / v_mov (12 vector instructions per frame of the 114; MI355_K1_UNIFORM_TILE=0 restores that).
-#ifndef MI355_K1_UNIFORM_TILE
-#define MI355_K1_UNIFORM_TILE 1
-#endif
-#if MI355_K1_UNIFORM_TILE
+    // updated with v_cndmask / v_add / v_mov (12 vector instructions per frame of the 114).
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#else
-    const uint32_t wave = threadIdx.x >> 6;
-#endif
     for (uint32_t tile = a.tile_begin + blockIdx.x * kWavesPerBlock + wave; tile < a.tile_end; tile += gridDim.x * kWavesPerBlock) {
         const uint32_t tile_off = tile * kTileBytes;
         const uint32_t byte_off = tile_off + (uint32_t)lane * 16u;
@@ -451,17 +403,24 @@ constexpr uint32_t kXTiles = 64;          // = one wave of k_scan_groups per gro
 constexpr uint32_t kScanChunk = 1024;     // groups scanned per pass of k_scan_groups
 constexpr uint32_t kScanDepth = 24;       // groups a wave of k_scan_groups has in flight at once (4 waves: 96 per round)
 
-// The one place where the library orders two agent-scope accesses without a release fence: `*slot = value` must be
-// visible to whoever sees the ticket this call takes.  The store is an agent-scope (write-through) store and the
-// lane waits for its completion (s_waitcnt vmcnt(0): the write has reached the level all XCDs share) before it
-// issues the relaxed ticket increment.  A release fence at agent scope would do the same and also write back this
-// XCD's whole L2, which at this point is full of k_diff_pack's fresh log lines: 19 us instead of 12 us per launch
-// (profiles/README.md).  This leans on gfx950's memory pipeline, not on the HIP memory model; the reader uses
-// agent-scope loads.  Guard: tests/soak.py (15 000 random batches against the oracle, clean).
-__device__ __forceinline__ uint32_t publish_then_take_ticket(uint32_t *slot, uint32_t value, uint32_t *ticket) {
-    __hip_atomic_store(slot, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// How the last workgroup of k_scan_groups learns the other workgroups' frame totals (they run on different XCDs, whose
+// L2s are not coherent for plain accesses) WITHOUT a release fence: a frame's total travels as ONE 64-bit atomic word
+// {total, epoch of this launch}, and the reader takes a word only when its epoch is this launch's.  Value and "it has
+// been written" are the same atomic object, so nothing has to be ordered between two locations: per-location coherence
+// and the eventual visibility of an atomic store are all the HIP / HSA memory model is asked for.  The ticket only
+// elects the reader.  (Rounds 3-4 ordered a relaxed 32-bit store before a relaxed ticket with s_waitcnt vmcnt(0), which
+// gfx950's write-through agent-scope stores honour but the memory model does not promise; an agent-scope release
+// fence instead writes back this XCD's whole L2 -- full of the next batch's fresh log lines when batches are pipelined
+// -- 19 us instead of 12 us per launch, profiles/README.md.)  The writer has issued its store before it takes its
+// ticket, so the reader's wait is bounded by that store's flight time; no workgroup waits for one that has not started.
+__device__ __forceinline__ void publish_total(uint64_t *slot, uint32_t total, uint32_t epoch) {
+    __hip_atomic_store(slot, (uint64_t)total | ((uint64_t)epoch << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t read_total(const uint64_t *slot, uint32_t epoch) {
+    uint64_t v;
+    do v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while ((uint32_t)(v >> 32) != epoch);
+    return (uint32_t)v;
 }
 
 // grid = T, block = 256: roff[t][r] = flagged bytes of frame t in the 16-tile ranges before r (4 per group),
@@ -470,14 +429,12 @@ __device__ __forceinline__ uint32_t publish_then_take_ticket(uint32_t *slot, uin
 // fourth range; the (at most kScanChunk) group sums are scanned in LDS.
 // The workgroup that finishes last (ticket counter, reset for the next launch) also scans the frame totals
 // into offsets[0..T]: one launch and one dependent round trip less than a separate kernel.
-__global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t *roff, uint32_t *totals,
+__global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t *roff, uint64_t *totals,
                                                      uint32_t ntiles, uint32_t ngroups, uint32_t *ticket,
-                                                     uint32_t *offsets) {
+                                                     uint32_t epoch, uint32_t *offsets) {
     static_assert(kXTiles == 64, "one wave reduces one group");
-#if MI355_XPRIO
     __builtin_amdgcn_s_setprio(3);   // pipelined batches: this short kernel gates the expansion; it must not queue for
                                      // issue slots behind the next batch's pack waves
-#endif
     __shared__ uint32_t s_sum[kScanChunk];
     __shared__ uint32_t s_part[kScanChunk][3];
     __shared__ uint32_t s_scan[5];
@@ -530,18 +487,19 @@ __global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t
         carry += total;
         __syncthreads();   // s_part / s_sum are rewritten by the next chunk
     }
-    // totals and the ticket are agent-scope atomics: the workgroups run on different XCDs, whose L2s are
-    // not coherent for plain accesses (publish_then_take_ticket says how the two are ordered).
+    // totals and the ticket are agent-scope atomics (publish_total says what orders them: nothing has to)
     __shared__ uint32_t s_is_last;
-    if (threadIdx.x == 0) s_is_last = publish_then_take_ticket(&totals[blockIdx.x], carry, ticket) == gridDim.x - 1;
+    if (threadIdx.x == 0) {
+        publish_total(&totals[blockIdx.x], carry, epoch);
+        s_is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
     __syncthreads();
     if (!s_is_last) return;
     const uint32_t nframes = gridDim.x;
     carry = 0;
     for (uint32_t base = 0; base < nframes; base += 256) {
         const uint32_t t = base + threadIdx.x;
-        const uint32_t v = t < nframes
-            ? __hip_atomic_load(&totals[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t v = t < nframes ? read_total(&totals[t], epoch) : 0u;
         uint32_t total;
         const uint32_t ex = block_exclusive_scan<4>(v, s_scan, total);
         if (t < nframes) offsets[t] = carry + ex;
@@ -555,10 +513,10 @@ __global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t
 
 uint32_t expand_groups(uint32_t ntiles) { return (ntiles + kXTiles - 1) / kXTiles; }
 
-hipError_t launch_scan(const uint4 *meta, uint32_t *roff, uint32_t *totals, uint32_t ntiles,
-                       int nframes, uint32_t *offsets, uint32_t *ticket, hipStream_t s) {
+hipError_t launch_scan(const uint4 *meta, uint32_t *roff, uint64_t *totals, uint32_t ntiles,
+                       int nframes, uint32_t *offsets, uint32_t *ticket, uint32_t epoch, hipStream_t s) {
     hipLaunchKernelGGL(k_scan_groups, dim3(nframes), dim3(256), 0, s, meta, roff, totals, ntiles,
-                       expand_groups(ntiles), ticket, offsets);
+                       expand_groups(ntiles), ticket, epoch, offsets);
     return hipGetLastError();
 }
 
@@ -601,37 +559,20 @@ __device__ __forceinline__ void lds_handoff() {
 // The packed stream is written once and not read again by this library's path: its stores are NON-TEMPORAL (round 4), so
 // that they do not push the logs -- written by the pack kernel, read back here one batch later -- out of the caches.
 // Measured (profiles/r04an, r04ao): the batch 4-5 % faster on the slower boards of the pool (0.502 -> 0.479 ms) and
-// sequentially (0.537 -> 0.514), unchanged on the fastest; MI355_XNT=0 builds the plain stores.  (Round 1 measured the
-// opposite for its 4-byte + 1-byte scattered stores, r01d: a non-temporal store wants whole 16-byte pieces.)
-#ifndef MI355_XSCALAR_PREFIX
-#define MI355_XSCALAR_PREFIX 1
-#endif
-#ifndef MI355_XNT
-#define MI355_XNT 1
-#endif
-#ifndef MI355_XLOGNT   // timing builds: 1 = code loads, 2 = record loads, 4 = meta loads of the expander non-temporal
-#define MI355_XLOGNT 0
-#endif
+// sequentially (0.537 -> 0.514), unchanged on the fastest.  (Round 1 measured the opposite for its 4-byte + 1-byte
+// scattered stores, r01d: a non-temporal store wants whole 16-byte pieces.)  The log itself is read with plain loads
+// (non-temporal ones: no gain, profiles/README.md r04).
 typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
 typedef uint32_t u32a1 __attribute__((aligned(1)));
 template <bool BYTE_ALIGNED>
 __device__ __forceinline__ void store_out4(uint8_t *p, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
     const u32x4 v = {x, y, z, w};
-#if MI355_XNT
     if (BYTE_ALIGNED) __builtin_nontemporal_store(v, reinterpret_cast<u32x4a1 *>(p));
     else __builtin_nontemporal_store(v, reinterpret_cast<u32x4a4 *>(p));
-#else
-    if (BYTE_ALIGNED) *reinterpret_cast<u32x4a1 *>(p) = v;
-    else *reinterpret_cast<u32x4a4 *>(p) = v;
-#endif
 }
 __device__ __forceinline__ void store_out1(uint8_t *p, uint32_t v) {   // any byte address
-#if MI355_XNT
     __builtin_nontemporal_store(v, reinterpret_cast<u32a1 *>(p));
-#else
-    *reinterpret_cast<u32a1 *>(p) = v;
-#endif
 }
 
 template <bool WIRE>
@@ -667,43 +608,15 @@ __device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint32_
     }
 }
 
-#ifndef MI355_XPRIO
-#define MI355_XPRIO 2
-#endif
-// Timing builds of the expander (tools/ab_build.sh, never shipped; outputs wrong by design): 1 = prologue only,
-// 2 = + code loads, 3 = + rounds, 4 = + queued lanes but no output stores, 9 = nothing but the dispatch of the grid.
-#ifndef MI355_XFABLATE
-#define MI355_XFABLATE 0
-#endif
-// Diagnostic build (-DMI355_XSTAMP=1, tools/ab_build.sh, never shipped): every wave of k_expand stamps s_memtime at
-// the ends of its phases into a buffer of their own; launch_expand prints the average wave-cycles per phase.
-#ifndef MI355_XSTAMP
-#define MI355_XSTAMP 0
-#endif
 // The expander declares 64 vector registers although it uses 50: beside the pack kernel of the next batch (4 waves of 72
 // registers per SIMD) three of its waves fit instead of four, and the pair is 1 % faster that way (0.539 against 0.546 ms
 // per batch, profiles/r04z: the more the expansion crowds the pack kernel, the more the pack kernel -- the longer of
 // the two -- stretches).  Alone the kernel runs 8 waves per SIMD either way.
-#ifndef MI355_XVGPRS
-#define MI355_XVGPRS 64
-#endif
-#if MI355_XSTAMP
-#define XSTAMP(k) do { __builtin_amdgcn_s_waitcnt(0xC07F); g_stamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
-__device__ uint64_t *g_stamp_buf;
-#else
-#define XSTAMP(k) do { } while (0)
-#endif
 constexpr uint32_t kWTiles = 16;             // tiles per item: one DPP row of lanes, a quarter of a scan group
 constexpr uint32_t kWStage = 1024;           // entries of the LDS stage = the most one tile can hold
 constexpr uint32_t kFList = 128;             // most multi-byte lanes of an item on the pair path (queued in 1 KiB of LDS)
 constexpr uint32_t kFStage = kWStage;        // most entries of an item on the pair path (10 bits of a queued lane's word)
-#ifndef MI355_XDENSE_WALK
-#define MI355_XDENSE_WALK 1
-#endif
-#ifndef MI355_XLIGHT
-#define MI355_XLIGHT 4
-#endif
-constexpr uint32_t kXLight = MI355_XLIGHT;   // lanes with more flagged bytes than this are expanded by 16 lanes
+constexpr uint32_t kXLight = 4;   // lanes with more flagged bytes than this are expanded by 16 lanes
 constexpr int kXHeavyMax = 12;               // ... unless a round of 64 lanes holds more of them than this
 
 // inclusive scan inside the first 16 lanes (one DPP row)
@@ -719,12 +632,11 @@ __device__ __forceinline__ int row_inclusive_scan(int v) {
 // stage[e], stage[e + 1], ... = (src16 + byte) << 8 | difference.  Lanes with up to kXLight flagged bytes walk
 // their bits; lanes with more (object edges among isolated bytes) would make the whole wave walk theirs, so they are
 // expanded by 16 lanes each, four records at a time through ds_bpermute -- unless the wave holds more than kXHeavyMax
-// of them (dense tiles): then everybody walks, all lanes busy for as many steps as the fullest lane has bytes.
+// of them (dense tiles): then every lane places its bytes by position.
 __device__ __forceinline__ void walk_records(uint32_t m16, uint32_t e, uint32_t src16, uint4 rec, uint32_t *stage, uint32_t lane) {
     const uint32_t cnt = (uint32_t)__builtin_popcount(m16);
-    uint64_t heavy = __ballot(cnt > kXLight);
-    const uint32_t light_max = __builtin_popcountll(heavy) > kXHeavyMax ? 16u : kXLight;
-    if (MI355_XDENSE_WALK && light_max == 16u) {
+    const uint64_t heavy = __ballot(cnt > kXLight);
+    if (__builtin_popcountll(heavy) > kXHeavyMax) {
         // DENSE wave (more than kXHeavyMax lanes with more than kXLight bytes: the synthetic worst cases, scene changes): every
         // lane places its bytes by position, straight code -- byte b of the record goes to e + (flagged bytes below b) if its
         // bit is set.  7 instructions per byte position and no loop, against 14 per iteration of the bit walk below (which
@@ -738,8 +650,7 @@ __device__ __forceinline__ void walk_records(uint32_t m16, uint32_t e, uint32_t 
         }
         return;
     }
-    if (light_max == 16u) heavy = 0;
-    if (cnt != 0u && cnt <= light_max) {
+    if (cnt != 0u && cnt <= kXLight) {
         uint32_t mm = m16, ee = e;
         do {
             const int b = __builtin_ctz(mm);
@@ -786,11 +697,7 @@ __device__ __forceinline__ void walk_records(uint32_t m16, uint32_t e, uint32_t 
 // wait per round (~150 cycles each; a third of the wave's lifetime, profiles/r04l_expand_stamps.log).
 // Fills stage[0 .. entries of the item) in output order.
 __device__ __forceinline__ void expand_pairs(const ExpandArgs &a, uint32_t mx, uint32_t my, uint32_t mz, uint2 *list, uint32_t *stage,
-                                             uint32_t lane
-#if MI355_XSTAMP
-                                             , uint64_t *g_stamp
-#endif
-                                             ) {
+                                             uint32_t lane) {
     const __amdgpu_buffer_rsrc_t codes = make_rsrc(a.codes, a.codes_bytes), recs = make_rsrc(a.rec, a.rec_bytes);
     // round r: the candidates of tile 2r in lanes 0 .. nc - 1, those of tile 2r + 1 behind them (together at most 64)
     uint32_t code[kWTiles / 2];
@@ -800,21 +707,16 @@ __device__ __forceinline__ void expand_pairs(const ExpandArgs &a, uint32_t mx, u
         const uint32_t nc_a = (uint32_t)__builtin_amdgcn_readlane((int)mz, 2 * r) >> 16, nc_b = (uint32_t)__builtin_amdgcn_readlane((int)mz, 2 * r + 1) >> 16;
         const uint32_t pc_a = (uint32_t)__builtin_amdgcn_readlane((int)mx, 2 * r), pc_b = (uint32_t)__builtin_amdgcn_readlane((int)mx, 2 * r + 1);
         const uint32_t off = lane >= nc_a ? lane4 + (pc_b - 4u * nc_a) : lane4 + pc_a;
-        code[r] = __builtin_amdgcn_raw_buffer_load_b32(codes, lane < nc_a + nc_b ? off : kOOB, 0, (MI355_XLOGNT & 1) ? 2 : 0);   // a lane without a candidate reads 0
+        code[r] = __builtin_amdgcn_raw_buffer_load_b32(codes, lane < nc_a + nc_b ? off : kOOB, 0, 0);   // a lane without a candidate reads 0
     }
-#if MI355_XFABLATE == 2
-    { uint32_t acc = 0;
+    if (kXAblate == 2) {   // lab: prologue + code loads
+        uint32_t acc = 0;
 #pragma unroll
-      for (uint32_t r = 0; r < kWTiles / 2; r++) acc ^= code[r];
-      if (acc == 0xfffffff0u) stage[0] = acc; }
-    return;
-#endif
+        for (uint32_t r = 0; r < kWTiles / 2; r++) acc ^= code[r];
+        if (acc == 0xfffffff0u) stage[0] = acc;
+        return;
+    }
     __builtin_amdgcn_sched_barrier(0);   // all eight requests leave before anything waits for the first
-#if MI355_XSTAMP
-    XSTAMP(2);                                    // code loads issued
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    XSTAMP(3);                                    // codes here
-#endif
     // entry offsets of all rounds first: eight independent DPP scans in one block of straight code fill each other's
     // wait states (a scan alone is 7 dependent steps with 2 idle cycles between them)
     uint32_t ent[kWTiles / 2];
@@ -824,7 +726,6 @@ __device__ __forceinline__ void expand_pairs(const ExpandArgs &a, uint32_t mx, u
         ent[r] = (uint32_t)wave_inclusive_scan((int)cnt) - cnt;
     }
     __builtin_amdgcn_sched_barrier(0);
-    XSTAMP(4);                                    // scans done
     // lanes with two or more flagged bytes are queued first, so that their records are on the way while the lanes
     // with one byte stage their entries
     uint32_t tail = 0;   // queued lanes (wave-uniform)
@@ -850,9 +751,8 @@ __device__ __forceinline__ void expand_pairs(const ExpandArgs &a, uint32_t mx, u
     lds_handoff();
     // the first 64 queued lanes' records (an item rarely queues more)
     const uint2 w0 = list[lane];
-    const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(recs, lane < tail ? (w0.x << 4) : kOOB, 0, (MI355_XLOGNT & 2) ? 2 : 0);
+    const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(recs, lane < tail ? (w0.x << 4) : kOOB, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    XSTAMP(5);                                    // queued, records requested
 #pragma unroll
     for (uint32_t r = 0; r < kWTiles / 2; r++) {
         const uint32_t c = code[r];
@@ -864,18 +764,13 @@ __device__ __forceinline__ void expand_pairs(const ExpandArgs &a, uint32_t mx, u
         if (m16 != 0u && (m16 & (m16 - 1u)) == 0u)
             stage[e] = ((src16 + (uint32_t)__builtin_ctz(m16)) << 8) | ((c >> 16) & 0xffu);   // kernels.cu:314-315
     }
-#if MI355_XFABLATE == 3
-    return;
-#endif
-#if MI355_XSTAMP
-    XSTAMP(6);                                    // one-byte lanes staged
-#endif
+    if (kXAblate == 3) return;   // lab: + rounds
     walk_records(lane < tail ? (w0.y & 0xffffu) : 0u, (w0.y >> 16) & 0x3ffu, ((w0.x >> 28) << 10) | ((w0.y >> 26) << 4),
                  make_uint4(q0.x, q0.y, q0.z, q0.w), stage, lane);
     for (uint32_t head = 64u; head < tail; head += 64u) {   // the rest, 64 at a time
         const bool on = head + lane < tail;
         const uint2 w = list[min(head + lane, kFList - 1u)];
-        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(recs, on ? (w.x << 4) : kOOB, 0, (MI355_XLOGNT & 2) ? 2 : 0);
+        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(recs, on ? (w.x << 4) : kOOB, 0, 0);
         walk_records(on ? (w.y & 0xffffu) : 0u, (w.y >> 16) & 0x3ffu, ((w.x >> 28) << 10) | ((w.y >> 26) << 4),
                      make_uint4(q.x, q.y, q.z, q.w), stage, lane);
     }
@@ -893,19 +788,19 @@ __device__ __forceinline__ void expand_tiles(const ExpandArgs &a, const uint4 *t
     const __amdgpu_buffer_rsrc_t codes = make_rsrc(a.codes, a.codes_bytes), recs = make_rsrc(a.rec, a.rec_bytes);
     // loads beyond the item (i >= 16) or without a candidate carry an offset outside the buffer: they return 0 and read nothing
     // tinfo[i].w = candidates | multi-byte lanes << 16.  A DENSE tile (64 multi-byte lanes) has records only (k_diff_pack,
-    // MI355_RECORD_ONLY): no codes are loaded, record `lane` is the lane's, its map are the record's non-zero bytes
+    // emit_step): no codes are loaded, record `lane` is the lane's, its map are the record's non-zero bytes
     auto load_code = [&](uint32_t i) {
         const uint4 ti = tinfo[i & (kWTiles - 1u)];
-        const bool dense = MI355_RECORD_ONLY && (ti.w >> 16) == 64u;
-        return __builtin_amdgcn_raw_buffer_load_b32(codes, (i < kWTiles && !dense && lane < (ti.w & 0xffffu)) ? ti.x + 4u * lane : kOOB, 0, (MI355_XLOGNT & 1) ? 2 : 0);
+        const bool dense = (ti.w >> 16) == 64u;
+        return __builtin_amdgcn_raw_buffer_load_b32(codes, (i < kWTiles && !dense && lane < (ti.w & 0xffffu)) ? ti.x + 4u * lane : kOOB, 0, 0);
     };
     auto load_rec = [&](uint32_t i, uint32_t c) {
         const uint4 ti = tinfo[i & (kWTiles - 1u)];
         const uint32_t m16 = c & 0xffffu;
-        const bool dense = MI355_RECORD_ONLY ? (ti.w >> 16) == 64u : ti.z == kTileBytes;
+        const bool dense = (ti.w >> 16) == 64u;
         // a dense tile: record `lane`; otherwise the record of a lane with two or more flagged bytes
         const uint32_t off = dense ? ti.y + 16u * lane : ((m16 & (m16 - 1u)) ? ti.y + 16u * ((c >> 16) & 0xffu) : kOOB);
-        return __builtin_amdgcn_raw_buffer_load_b128(recs, i < kWTiles ? off : kOOB, 0, (MI355_XLOGNT & 2) ? 2 : 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(recs, i < kWTiles ? off : kOOB, 0, 0);
     };
     uint32_t carry = 0, flushed = 0;   // entries of the item expanded so far / already stored (wave-uniform)
     uint32_t c0 = load_code(0), c1 = load_code(1);
@@ -917,7 +812,7 @@ __device__ __forceinline__ void expand_tiles(const ExpandArgs &a, const uint4 *t
         const uint4 ti = tinfo[i];
         const uint32_t ncm = (uint32_t)__builtin_amdgcn_readfirstlane((int)ti.w), bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)ti.z);
         const uint32_t nc = ncm & 0xffffu;
-        const bool dense = MI355_RECORD_ONLY && (ncm >> 16) == 64u;   // records only, no codes
+        const bool dense = (ncm >> 16) == 64u;   // records only, no codes
         if (nc != 0u) {
             const bool full = bytes == kTileBytes;   // every byte of the tile flagged: its 64 records are the difference bytes
             if (full || carry - flushed + bytes > kWStage) {   // make room (a full tile goes straight out: empty the stage first)
@@ -960,26 +855,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     __shared__ __attribute__((aligned(16))) uint2 s_list[kFList];         // pair path: the item's queued (multi-byte) lanes; tile path: the 16 tiles' facts
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[kWStage];    // (byte index relative to the item's first tile) << 8 | difference
     // 5120 bytes of LDS: 32 single-wave workgroups per CU
-#if MI355_XPRIO
     // beside the next batch's pack kernel (pipelined batches) these short, latency-bound waves must not queue for
     // issue slots behind the older, issue-hungry pack waves
-    __builtin_amdgcn_s_setprio(MI355_XPRIO);
-#endif
+    __builtin_amdgcn_s_setprio(2);
     const uint32_t lane = threadIdx.x;
-#if MI355_XFABLATE == 9
-    return;
-#endif
-#if MI355_XVGPRS == 64
-    asm volatile("v_mov_b32 v63, 0" ::: "v63");
-#elif MI355_XVGPRS == 72
-    asm volatile("v_mov_b32 v71, 0" ::: "v71");
-#elif MI355_XVGPRS == 80
-    asm volatile("v_mov_b32 v79, 0" ::: "v79");
-#endif
-#if MI355_XSTAMP
-    uint64_t g_stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    XSTAMP(0);                                    // wave started
-#endif
+    if (kXAblate == 9) return;   // lab: nothing but the dispatch of the grid
+    asm volatile("v_mov_b32 v63, 0" ::: "v63");   // 64 declared vector registers (above)
     const uint32_t t = blockIdx.y, sub = blockIdx.x;
     if (sub * kWTiles >= a.ntiles) return;   // grid.x is padded to a multiple of 8 (see launch_expand)
     const uint32_t ngroups = (a.ntiles + kXTiles - 1) / kXTiles;
@@ -987,24 +868,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // lanes << 16}; the other lanes (and tiles beyond the frame) read nothing and get zeros
     const uint32_t tile = sub * kWTiles + lane;
     const __amdgpu_buffer_rsrc_t metas = make_rsrc(a.meta + (size_t)t * a.ntiles, a.ntiles * 16u);
-    const u32x4 mq = __builtin_amdgcn_raw_buffer_load_b128(metas, lane < kWTiles ? tile * 16u : kOOB, 0, (MI355_XLOGNT & 4) ? 2 : 0);
+    const u32x4 mq = __builtin_amdgcn_raw_buffer_load_b128(metas, lane < kWTiles ? tile * 16u : kOOB, 0, 0);
     // The two prefixes are wave-uniform words that only this kernel's LAST step needs (the destination of the stores): they
     // are read with SCALAR loads (constant address space: nothing writes them while this kernel runs), which leave together
     // with the meta load and are waited for on their own counter.  As plain loads the compiler placed them behind the
     // early exit below and waited for them before the code loads left: a fourth dependent round trip in a wave's life
     // (meta -> prefixes -> codes -> records).
-#if MI355_XSCALAR_PREFIX
     typedef const __attribute__((address_space(4))) uint32_t *cptr;
     const cptr offs_c = (cptr)(uintptr_t)a.offsets, roff_c = (cptr)(uintptr_t)a.roff;
     const uint32_t off_t = offs_c[t];                                           // entries of the frames before t
     const uint32_t roff = roff_c[(size_t)t * ngroups * 4u + sub];               // entries of frame t before the item's tiles
     const uint32_t n_t = WIRE ? offs_c[t + 1] - off_t : 0u;                     // entries of frame t
     asm volatile("" ::"s"(off_t), "s"(roff), "s"(n_t));   // requested HERE, beside the meta load (not behind the early exit below)
-#else
-    const uint32_t off_t = a.offsets[t];                                        // entries of the frames before t
-    const uint32_t roff = a.roff[(size_t)t * ngroups * 4u + sub];               // entries of frame t before the item's tiles
-    const uint32_t n_t = WIRE ? a.offsets[t + 1] - off_t : 0u;                  // entries of frame t
-#endif
     const uint4 m = make_uint4(mq.x, mq.y, mq.z, mq.w);
     size_t head = 0;
     if (WIRE) {
@@ -1019,7 +894,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const uint32_t nent = tot & 0xffffu;
     if (nent == 0u) return;
     const uint32_t dst0 = off_t + roff;   // < 2^32: the batch total is below 2^32
-    XSTAMP(1);                                    // meta words, offsets here
     uint8_t *w_xs = nullptr, *w_df = nullptr;
     size_t w_room = 0;
     if (WIRE) {
@@ -1041,28 +915,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         expand_tiles<WIRE>(a, s_tinfo, s_stage, lane, xs0, dst0, w_xs, w_df, w_room);
         return;
     }
-#if MI355_XFABLATE != 1
-    expand_pairs(a, m.x, m.y, ((bincl - both) & 0xffffu) | (nc << 16), s_list, s_stage, lane
-#if MI355_XSTAMP
-                 , g_stamp
-#endif
-                 );
+    if (kXAblate == 1) return;   // lab: prologue only
+    expand_pairs(a, m.x, m.y, ((bincl - both) & 0xffffu) | (nc << 16), s_list, s_stage, lane);
     lds_handoff();
-    XSTAMP(7);                                    // queued lanes expanded
-#if MI355_XFABLATE < 2
-    flush_entries<WIRE>(a, s_stage, 0u, nent, xs0, dst0, w_xs, w_df, w_room);
-#endif
-#endif
-#if MI355_XSTAMP
-    XSTAMP(8);                                    // stores issued
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    XSTAMP(9);                                    // stores done
-    if (lane == 0) {
-        uint64_t *o = g_stamp_buf + ((size_t)t * gridDim.x + sub) * 10;
-#pragma unroll
-        for (int k = 0; k < 10; k++) o[k] = g_stamp[k];
-    }
-#endif
+    if (kXAblate < 2) flush_entries<WIRE>(a, s_stage, 0u, nent, xs0, dst0, w_xs, w_df, w_room);
 }
 
 hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s) {
@@ -1074,43 +930,10 @@ hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s) {
     // 1.87 M -> 3.33 M per batch, L2 hit rate 55 % -> 38 %, profiles/r04_tcc_grid_padding.txt).
     const uint32_t gx = (a.ntiles + kWTiles - 1) / kWTiles;
     const dim3 grid((gx + 7u) / 8u * 8u, nframes);
-#if MI355_XSTAMP
-    static uint64_t *buf = nullptr;
-    static size_t cap = 0;
-    const size_t words = (size_t)grid.x * grid.y * 10;
-    if (words > cap) {
-        if (buf) (void)hipFree(buf);
-        if (hipMalloc((void **)&buf, words * 8) != hipSuccess) return hipErrorOutOfMemory;
-        cap = words;
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof buf);
-    }
-    (void)hipMemsetAsync(buf, 0, words * 8, s);
-#endif
     if (a.wire)
         hipLaunchKernelGGL(k_expand<true>, grid, dim3(64), 0, s, a);
     else
         hipLaunchKernelGGL(k_expand<false>, grid, dim3(64), 0, s, a);
-#if MI355_XSTAMP
-    static int calls = 0;
-    if (++calls == 8) {   // one steady-state launch
-        (void)hipStreamSynchronize(s);
-        std::vector<uint64_t> h(words);
-        (void)hipMemcpy(h.data(), buf, words * 8, hipMemcpyDeviceToHost);
-        double sum[10] = {0}; size_t n = 0; uint64_t first = ~0ull, last = 0;
-        for (size_t i = 0; i < words; i += 10) {
-            if (!h[i + 9]) continue;   // the tile path, or an empty item
-            for (int k = 1; k < 10; k++) sum[k] += (double)(h[i + k] - h[i + k - 1]);
-            first = h[i] < first ? h[i] : first; last = h[i + 9] > last ? h[i + 9] : last;
-            n++;
-        }
-        fprintf(stderr, "xstamp: %zu waves on the pair path, kernel span %.0f cycles; average wave-cycles per phase:\n", n, (double)(last - first));
-        const char *name[10] = {"", "start -> meta+offsets here", "-> code loads issued", "-> codes here", "-> scans done", "-> queued, records asked",
-                                "-> one-byte lanes staged", "-> queued lanes expanded", "-> stores issued", "-> stores done"};
-        double tot = 0;
-        for (int k = 1; k < 10; k++) { fprintf(stderr, "  %-28s %8.0f\n", name[k], sum[k] / n); tot += sum[k] / n; }
-        fprintf(stderr, "  %-28s %8.0f\n", "wave lifetime", tot);
-    }
-#endif
     return hipGetLastError();
 }
 

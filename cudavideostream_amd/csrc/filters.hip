@@ -835,18 +835,11 @@ __device__ __forceinline__ uint32_t f32_to_u8(float f) {
 // now integral value exactly, saturates to 0..255 -- negatives and NaN to 0 -- and drops it into its byte): two
 // instructions per byte instead of conversion, minimum and shift-or.  Same results as f32_to_u8 for every float
 // (tests: test_conv3x3_sharpen_and_edge_kernels_saturate_the_same_way, the 1080p / fuzz parity against the oracle).
-#ifndef MI355_CONV_PK_U8
-#define MI355_CONV_PK_U8 1
-#endif
 __device__ __forceinline__ uint32_t f32x4_to_u8x4(float a, float b, float c, float d) {
-#if MI355_CONV_PK_U8
     uint32_t r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(a), 0u, 0u);
     r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(b), 1u, r);
     r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(c), 2u, r);
     return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(d), 3u, r);
-#else
-    return f32_to_u8(a) | (f32_to_u8(b) << 8) | (f32_to_u8(c) << 16) | (f32_to_u8(d) << 24);
-#endif
 }
 
 __device__ __forceinline__ float byte_f(uint32_t dw, int b) {  // b is a compile-time constant
@@ -855,124 +848,146 @@ __device__ __forceinline__ float byte_f(uint32_t dw, int b) {  // b is a compile
 
 // k_conv3x3_strip (rows 16-byte aligned, i.e. 3*w % 16 == 0 -- 1080p and 4K; k_conv3x3_any is the byte-wise
 // form for every other geometry): a lane owns a column strip of 16 bytes x kStripRows rows and walks it
-// top to bottom.  An input row is converted once (22 floats: 16 bytes + 3 either side, the
-// neighbours' bytes re-read through the cache) and serves three output rows: as the bottom row of r-1
+// top to bottom.  An input row is converted once and serves three output rows: as the bottom row of r-1
 // (taps k6..k8, after which r-1 is complete and stored), the middle row of r (k3..k5) and the top row of
 // r+1 (k0..k2) -- for every output the nine multiply-then-add steps happen in the reference's i-major,
 // j-minor order.  No LDS, no barriers.  SYM: k0=k2=k6=k8 and k1=k3=k5=k7 bit for bit (the reference's
-// Gaussian, server.cpp:20-36): a product k*in is the same float wherever it is used, so 76 products per
-// row serve the 144 tap positions.  The kernel is VALU-bound (tools/ubench/valu_rate.hip: on gfx950 a
-// byte<->float conversion costs a wave as much as two multiplies, and packed fp32 instructions issue at
-// half the rate of plain ones, i.e. no faster per element): ~13 instructions per output byte (SYM), ~15
-// (general), against 18 for the LDS-tiled row kernel it replaced (4.24 -> 3.53 us per 1080p frame).
-#ifndef MI355_CONV_NT_STORE
-#define MI355_CONV_NT_STORE 0
-#endif
-#ifndef MI355_CONV_STRIP
-#define MI355_CONV_STRIP 30
-#endif
-constexpr int kStripRows = MI355_CONV_STRIP;
+// Gaussian, server.cpp:20-36): a product k*in is the same float wherever it is used.
+//
+// Round 5, after the first counter pass on this kernel (profiles/r05_conv_sq.txt: a wave spent 48 % of its life in
+// s_waitcnt and only 11 % waiting to issue -- the kernel was bound by the LATENCY of its row loads, not by its
+// arithmetic: with two waves per SIMD a row's 170 instructions take ~0.6 us, and that was all the head start the
+// next row's load had):
+//   * rows are requested THREE rows ahead (a ring of three rows in flight, 15 registers);
+//   * a row is ONE 16-byte load per lane: the three bytes either side come from the neighbour lanes' registers
+//     (DPP wave_shr:1 / wave_shl:1 of the dword next to the seam) instead of two more dword loads per lane through
+//     the cache (1.34 x the frame's bytes fetched, profiles/r04_filters_pmc.json); only lanes 0 and 63 fetch the
+//     dword beyond the wave's 1 KiB (one load instruction, every other lane's offset is out of range and reads nothing);
+//   * loads and stores go through buffer descriptors: rows outside the image are a descriptor of zero records (the
+//     hardware returns zeros: kernels.cu:111-115), lanes beyond the row end carry an out-of-range offset -- no address
+//     arithmetic per lane, no zeroing instructions, no divergence;
+//   * every input byte is converted ONCE: the middle tap's edge-weight product k1 * centre byte IS the product the
+//     corner/edge taps of the neighbouring outputs computed (same float), so the centre bytes need no second
+//     conversion in their own pairing (packed fp32 operands must be even-aligned register pairs: round 1 converted the
+//     16 centre bytes twice to have them in both pairings); the adds that take such an odd-aligned pair are plain
+//     v_add_f32, the others packed.
+constexpr int kStripRows = 30;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t cv_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t conv_rsrc(const void *p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);   // raw buffer, 32-bit format
+}
+
+// One fp32 add / multiply on single registers.  Written as an instruction because the compiler otherwise re-pairs these
+// operations into packed ones and moves their operands into even-aligned register pairs first (33 moves per row).
+__device__ __forceinline__ float add1(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float mul1(float a, float b) {
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 #ifndef MI355_CONV_WAVES
-#define MI355_CONV_WAVES 2
+#define MI355_CONV_WAVES 4
 #endif
-#ifndef MI355_CONV_PAIRS
-#define MI355_CONV_PAIRS 8
-#endif
-constexpr int kConvPairs = MI355_CONV_PAIRS;   // output pairs per lane: 8 = 16-byte strips, 4 = 8-byte strips
-
-template <bool SYM, int NP>
+template <bool SYM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MI355_CONV_WAVES, MI355_CONV_WAVES)))
 void k_conv3x3_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, const float *k9, size_t stride) {
-    constexpr int LB = 2 * NP;      // bytes per lane and row
-    constexpr int NW = NP / 2;      // dwords per lane and row
-    in += (size_t)blockIdx.z * stride;
-    out += (size_t)blockIdx.z * stride;
-    const int xb = (blockIdx.x * 64 + threadIdx.x) * LB;
-    if (xb >= rowbytes) return;
+    constexpr int NP = 8;           // output pairs per lane and row (16 bytes)
+    constexpr uint32_t kOut = 0x80000000u;   // beyond every frame (mi355_create: N < 2^31); + a row offset it does not wrap
+    const uint32_t lane = threadIdx.x;
+    const uint32_t frame_bytes = (uint32_t)rowbytes * (uint32_t)h;
+    const uint8_t *src = in + (size_t)blockIdx.z * stride;
+    const __amdgpu_buffer_rsrc_t dst = conv_rsrc(out + (size_t)blockIdx.z * stride, frame_bytes);
+    const uint32_t xb = (blockIdx.x * 64u + lane) * 16u;
+    const bool live = xb < (uint32_t)rowbytes;
+    const uint32_t col = live ? xb : kOut;   // a lane beyond the row end reads zeros and stores nothing
+    // the dword beyond the wave's own kilobyte: lane 0 needs the one to its left, lane 63 the one to its right (zero
+    // outside the row, kernels.cu:111-115); the other lanes read nothing
+    const bool has_l = live && xb > 0u, has_r = live && xb + 16u < (uint32_t)rowbytes;
+    const uint32_t edge_col = lane == 0u ? (has_l ? xb - 4u : kOut) : (lane == 63u && has_r ? xb + 16u : kOut);
+    const uint32_t mask_l = lane == 0u ? ~0u : 0u, mask_r = lane == 63u ? ~0u : 0u;
     const int y0 = blockIdx.y * kStripRows;
     const int y1 = min(y0 + kStripRows, h);
     float kk[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) kk[i] = k9[i];
-    const bool has_l = xb > 0, has_r = xb + LB < rowbytes;
 
-    // Loads are unconditional (row and halo addresses clamped into the frame, the values zeroed afterwards):
-    // a load behind a branch makes the compiler wait for every outstanding load (s_waitcnt vmcnt(0)), i.e.
-    // the next row could not be in flight while this one is computed.
-    struct Row { uint32_t m[NW]; uint32_t l, r; };
+    struct Row { uint32_t m[4]; uint32_t edge; };
     auto load_row = [&](int r) {
-        const bool inside = r >= 0 && r < h;                        // zero outside the image, kernels.cu:111-115
-        const uint8_t *p = in + (size_t)min(max(r, 0), h - 1) * rowbytes + xb;
+        // a row outside the image: a descriptor without records, every load returns zeros (no traffic)
+        const bool inside = r >= 0 && r < h;
+        const __amdgpu_buffer_rsrc_t d = conv_rsrc(src, inside ? frame_bytes : 0u);
+        const uint32_t rowoff = (uint32_t)min(max(r, 0), h - 1) * (uint32_t)rowbytes;
         Row v;
-        if (NW == 4) {
-            const uint4 t = *reinterpret_cast<const uint4 *>(p);
-            v.m[0] = t.x; v.m[1] = t.y; v.m[NW - 2] = t.z; v.m[NW - 1] = t.w;
-        } else {
-            const uint2 t = *reinterpret_cast<const uint2 *>(p);
-            v.m[0] = t.x; v.m[NW - 1] = t.y;
-        }
-        v.l = *reinterpret_cast<const uint32_t *>(has_l ? p - 4 : p);
-        v.r = *reinterpret_cast<const uint32_t *>(has_r ? p + LB : p);
-#pragma unroll
-        for (int d = 0; d < NW; d++)
-            if (!inside) v.m[d] = 0;
-        if (!inside || !has_l) v.l = 0;
-        if (!inside || !has_r) v.r = 0;
+        const cv_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(d, col + rowoff, 0, 0);
+        v.edge = __builtin_amdgcn_raw_buffer_load_b32(d, edge_col + rowoff, 0, 0);
+        v.m[0] = t.x; v.m[1] = t.y; v.m[2] = t.z; v.m[3] = t.w;
         return v;
     };
     // One input row: B = accumulators of output row r-1, M = of row r, T = (fresh) of row r+1, as NP pairs
-    // of adjacent outputs (v_pk_mul_f32 / v_pk_add_f32 take even-aligned register pairs, so the pairing is
-    // spelled out).  With f[n] = byte xb - 3 + n, output pair q = outputs (2q, 2q+1) takes its left and right
-    // taps from e[q] = (f[2q], f[2q+1]) and e[q+3], and its middle tap from the centre bytes in their natural
-    // pairs c[q] = (f[2q+3], f[2q+4]): the centre bytes are needed in both pairings.
+    // of adjacent outputs.  With f[n] = byte xb - 3 + n (n = 0..21), output pair q = outputs (2q, 2q+1) takes its left
+    // and right taps from e[q] = (f[2q], f[2q+1]) and e[q+3], and its middle tap from (f[2q+3], f[2q+4]) = (e[q+1].y,
+    // e[q+2].x): an odd-aligned pair.
     auto step = [&](int r, const Row &v, f32x2 (&B)[NP], f32x2 (&M)[NP], f32x2 (&T)[NP]) {
-        f32x2 e[NP + 3], c[NP];
-        e[0] = f32x2{byte_f(v.l, 1), byte_f(v.l, 2)};
-        e[1] = f32x2{byte_f(v.l, 3), byte_f(v.m[0], 0)};
+        // the neighbour lanes' dwords next to the seam (lanes without a neighbour get 0), lanes 0 / 63: the fetched one
+        uint32_t l = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.m[3], 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+        uint32_t rr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.m[0], 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+        l = (v.edge & mask_l) | l;
+        rr = (v.edge & mask_r) | rr;
+        f32x2 e[NP + 3];
+        e[0] = f32x2{byte_f(l, 1), byte_f(l, 2)};
+        e[1] = f32x2{byte_f(l, 3), byte_f(v.m[0], 0)};
 #pragma unroll
-        for (int d = 0; d < NW; d++) {
-            c[2 * d] = f32x2{byte_f(v.m[d], 0), byte_f(v.m[d], 1)};
-            c[2 * d + 1] = f32x2{byte_f(v.m[d], 2), byte_f(v.m[d], 3)};
+        for (int d = 0; d < 4; d++) {
             e[2 + 2 * d] = f32x2{byte_f(v.m[d], 1), byte_f(v.m[d], 2)};
-            e[3 + 2 * d] = f32x2{byte_f(v.m[d], 3), d + 1 < NW ? byte_f(v.m[d + 1 < NW ? d + 1 : d], 0) : byte_f(v.r, 0)};
+            e[3 + 2 * d] = f32x2{byte_f(v.m[d], 3), d + 1 < 4 ? byte_f(v.m[d + 1 < 4 ? d + 1 : d], 0) : byte_f(rr, 0)};
         }
-        e[NP + 2] = f32x2{byte_f(v.r, 1), byte_f(v.r, 2)};
+        e[NP + 2] = f32x2{byte_f(rr, 1), byte_f(rr, 2)};
         if (SYM) {
             f32x2 pc[NP + 3], pe[NP + 3];   // corner * e, edge * e
+            float kc;                       // the centre weight in a vector register (add1 / mul1 take vector operands)
+            asm("v_mov_b32 %0, %1" : "=v"(kc) : "s"(kk[4]));
 #pragma unroll
             for (int q = 0; q < 3; q++) { pc[q] = kk[0] * e[q]; pe[q] = kk[1] * e[q]; }
 #pragma unroll
             for (int q = 0; q < NP; q++) {
                 pc[q + 3] = kk[0] * e[q + 3];
                 pe[q + 3] = kk[1] * e[q + 3];
-                const f32x2 po = kk[1] * c[q], pm = kk[4] * c[q];
-                B[q] = ((B[q] + pc[q]) + po) + pc[q + 3];             // k6 k7 k8
-                M[q] = ((M[q] + pe[q]) + pm) + pe[q + 3];             // k3 k4 k5
-                T[q] = (pc[q] + po) + pc[q + 3];                      // k0 k1 k2 (0 + p == p up to the sign of zero)
+                // middle taps: edge weight * centre bytes = what pe already holds; centre weight: two plain multiplies
+                const float pox = pe[q + 1].y, poy = pe[q + 2].x;
+                const float pmx = mul1(kc, e[q + 1].y), pmy = mul1(kc, e[q + 2].x);
+                f32x2 b = B[q] + pc[q];                                // k6
+                b.x = add1(b.x, pox); b.y = add1(b.y, poy);            // k7
+                B[q] = b + pc[q + 3];                                  // k8
+                f32x2 m = M[q] + pe[q];                                // k3
+                m.x = add1(m.x, pmx); m.y = add1(m.y, pmy);            // k4
+                M[q] = m + pe[q + 3];                                  // k5
+                f32x2 t;
+                t.x = add1(pc[q].x, pox); t.y = add1(pc[q].y, poy);    // k0 k1 (0 + p == p up to the sign of zero)
+                T[q] = t + pc[q + 3];                                  // k2
             }
         } else {
 #pragma unroll
             for (int q = 0; q < NP; q++) {
-                B[q] = ((B[q] + kk[6] * e[q]) + kk[7] * c[q]) + kk[8] * e[q + 3];
-                M[q] = ((M[q] + kk[3] * e[q]) + kk[4] * c[q]) + kk[5] * e[q + 3];
-                T[q] = (kk[0] * e[q] + kk[1] * c[q]) + kk[2] * e[q + 3];
+                const f32x2 c = f32x2{e[q + 1].y, e[q + 2].x};
+                B[q] = ((B[q] + kk[6] * e[q]) + kk[7] * c) + kk[8] * e[q + 3];
+                M[q] = ((M[q] + kk[3] * e[q]) + kk[4] * c) + kk[5] * e[q + 3];
+                T[q] = (kk[0] * e[q] + kk[1] * c) + kk[2] * e[q + 3];
             }
         }
         if (r - 1 >= y0) {   // output row r-1 is complete (r <= y1 here)
-            uint32_t o[NW];
-#pragma unroll
-            for (int d = 0; d < NW; d++)
-                o[d] = f32x4_to_u8x4(B[2 * d].x, B[2 * d].y, B[2 * d + 1].x, B[2 * d + 1].y);   // :131-133
-            uint8_t *dst = out + (size_t)(r - 1) * rowbytes + xb;
-#if MI355_CONV_NT_STORE
-            typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-            if (NW == 4) __builtin_nontemporal_store(v4{o[0], o[1], o[NW - 2], o[NW - 1]}, reinterpret_cast<v4 *>(dst));
-#else
-            if (NW == 4) *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[NW - 2], o[NW - 1]);
-#endif
-            else *reinterpret_cast<uint2 *>(dst) = make_uint2(o[0], o[NW - 1]);
+            cv_u32x4 o;
+            o.x = f32x4_to_u8x4(B[0].x, B[0].y, B[1].x, B[1].y);   // :131-133
+            o.y = f32x4_to_u8x4(B[2].x, B[2].y, B[3].x, B[3].y);
+            o.z = f32x4_to_u8x4(B[4].x, B[4].y, B[5].x, B[5].y);
+            o.w = f32x4_to_u8x4(B[6].x, B[6].y, B[7].x, B[7].y);
+            __builtin_amdgcn_raw_buffer_store_b128(o, dst, col + (uint32_t)(r - 1) * (uint32_t)rowbytes, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);   // one row at a time: fewer products live at once
     };
@@ -980,17 +995,19 @@ void k_conv3x3_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, const
     f32x2 a0[NP], a1[NP], a2[NP];
 #pragma unroll
     for (int q = 0; q < NP; q++) a0[q] = a1[q] = a2[q] = f32x2{0.0f, 0.0f};
-    Row cur = load_row(y0 - 1);
+    // rows y0-1 .. y1 are walked; three rows are in flight ahead of the one being computed (requests for rows beyond y1
+    // read rows of the strip below or, beyond the image, nothing)
+    Row q0 = load_row(y0 - 1), q1 = load_row(y0), q2 = load_row(y0 + 1);
     for (int r = y0 - 1; r <= y1; r += 3) {      // the three accumulator sets rotate through the roles
-        Row nxt = load_row(r + 1);
-        step(r, cur, a0, a1, a2);
+        const Row n0 = load_row(r + 3);
+        step(r, q0, a0, a1, a2);
         if (r + 1 > y1) break;
-        cur = load_row(r + 2);
-        step(r + 1, nxt, a1, a2, a0);
+        const Row n1 = load_row(r + 4);
+        step(r + 1, q1, a1, a2, a0);
         if (r + 2 > y1) break;
-        nxt = load_row(r + 3);
-        step(r + 2, cur, a2, a0, a1);
-        cur = nxt;
+        const Row n2 = load_row(r + 5);
+        step(r + 2, q2, a2, a0, a1);
+        q0 = n0; q1 = n1; q2 = n2;
     }
 }
 
@@ -1092,11 +1109,11 @@ hipError_t launch_conv3x3(const uint8_t *in, uint8_t *out, int w, int h, const f
     if (w <= 0 || h <= 0 || fb.nframes <= 0) return hipSuccess;
     const int rowbytes = 3 * w;
     if (rowbytes % 16 == 0 && aligned16(in) && aligned16(out) && fb.stride % 16 == 0) {
-        const dim3 grid((rowbytes / (2 * kConvPairs) + 63) / 64, (h + kStripRows - 1) / kStripRows, (unsigned)fb.nframes);
+        const dim3 grid((rowbytes / 16 + 63) / 64, (h + kStripRows - 1) / kStripRows, (unsigned)fb.nframes);
         if (k9_symmetric)
-            hipLaunchKernelGGL((k_conv3x3_strip<true, kConvPairs>), grid, dim3(64), 0, s, in, out, rowbytes, h, k9, fb.stride);
+            hipLaunchKernelGGL((k_conv3x3_strip<true>), grid, dim3(64), 0, s, in, out, rowbytes, h, k9, fb.stride);
         else
-            hipLaunchKernelGGL((k_conv3x3_strip<false, kConvPairs>), grid, dim3(64), 0, s, in, out, rowbytes, h, k9, fb.stride);
+            hipLaunchKernelGGL((k_conv3x3_strip<false>), grid, dim3(64), 0, s, in, out, rowbytes, h, k9, fb.stride);
     } else {
         const dim3 grid((w + kConvTW - 1) / kConvTW, (h + kConvRows - 1) / kConvRows, (unsigned)fb.nframes);
         hipLaunchKernelGGL(k_conv3x3_any, grid, dim3(256), 0, s, in, out, w, h, k9, fb.stride);

@@ -23,7 +23,7 @@ struct PackArgs {
     int32_t thr;           // threshold
     uint32_t ntiles;       // W = ceil(n / 1024)
     uint32_t tile_begin;   // this launch packs tiles [tile_begin, tile_end): the whole frame, or one part of it when a
-    uint32_t tile_end;     // pipelined batch is packed by two staggered launches (core.hip, MI355_SPLIT)
+    uint32_t tile_end;     // pipelined batch is packed by two staggered launches (core.hip, MI355_OPT_SPLIT_PCT)
     uint32_t *codes;       // code log: T/4 chunks x W tiles x 256 codes (one per candidate lane)
     uint4 *rec;            // record log: T chunks x W tiles x 64 records of 16 masked diff bytes (multi-byte lanes)
     uint4 *meta;           // [T][W]: {code position, record position, flagged bytes, candidates | multi-byte lanes << 16}
@@ -47,61 +47,6 @@ struct ExpandArgs {
     size_t capacity;          // entries of out_xs/out_diff, or bytes of wire
 };
 
-// The one-kernel stream form (diff_fused.hip).  sync words are zeroed before every launch.
-struct FusedArgs {
-    const uint8_t *cur;
-    uint8_t *state;
-    size_t stride;
-    uint32_t n;            // bytes per frame, a multiple of 16
-    int32_t nframes;
-    int32_t thr;
-    uint32_t ntiles;       // W
-    uint32_t nwg;          // workgroups that own tiles = ceil(W / 4)
-    uint32_t ngroups;      // ceil(nwg / 64) <= 64
-    uint32_t tag;          // 1..65535, different for consecutive launches
-    uint32_t *wgsum;       // [T][nwg]     flagged bytes of a workgroup's tiles per frame | tag << 16
-    uint32_t *gsum;        // [T][ngroups] the same added up per group of 64 workgroups | contributors << 20 (zeroed)
-    uint32_t *garrive;     // [ceil(T/8)][ngroups] workgroups of the group that have published the epoch (zeroed)
-    uint32_t *arrive;      // [ceil(T/8)]  groups that are complete                       (zeroed)
-    uint32_t *ready;       // [nwg][32]    per workgroup, own line: tag << 16 | epochs everybody has published
-    uint32_t *status;      // [1]          != 0: a bounded wait expired                  (zeroed)
-    uint32_t *offsets;     // [T+1] out
-    int32_t *out_xs;
-    uint8_t *out_diff;
-    size_t capacity;
-    uint4 *spill;          // [W][16][64] raw records of dense frames
-    uint32_t *ovf;         // [W][2][kOvf] FIFO entries beyond the LDS capacity
-};
-uint32_t fused_groups(uint32_t nwg);
-size_t fused_spill_records(uint32_t ntiles);
-size_t fused_ovf_entries(uint32_t ntiles);
-uint32_t fused_epochs(int nframes);
-size_t fused_ready_words(uint32_t nwg);
-uint32_t fused_capacity(int device);
-hipError_t launch_diff_fused(const FusedArgs &a, hipStream_t s);
-
-// The one-pass pair form (diff_chain.hip): chained scan, descriptors tagged per launch.
-struct ChainArgs {
-    const uint8_t *cur, *prev;
-    size_t stride;
-    uint32_t n;            // bytes per frame, a multiple of 16
-    int32_t nframes;
-    int32_t thr;
-    uint32_t ntiles;       // W
-    uint32_t ngroups;      // blocks (64 tiles) per frame
-    uint32_t tag;          // 1..65535, different for consecutive launches
-    uint64_t *desc;        // [T][ngroups] value | tag << 32 | state << 48 (1 aggregate, 2 inclusive prefix in the frame)
-    uint64_t *fdesc;       // [T]          entries of frames 0..t | tag << 32 | 2 << 48
-    uint32_t *status;      // [1]          != 0: a bounded wait expired (zeroed)
-    uint32_t *offsets;     // [T+1] out
-    int32_t *out_xs;
-    uint8_t *out_diff;
-    size_t capacity;
-};
-uint32_t chain_groups(uint32_t ntiles);
-uint32_t chain_capacity(int device);
-hipError_t launch_diff_chain(const ChainArgs &a, uint32_t resident_workgroups, hipStream_t s);
-
 // core.hip, for the other translation units of the library (group.hip)
 }  // namespace mi355
 struct mi355_core;
@@ -114,9 +59,9 @@ int core_device(const ::mi355_core *c);
 hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, bool pair_once /* pair mode: no frame is an operand twice */,
                             uint32_t max_blocks /* 0: one tile per wave */, hipStream_t s);
 uint32_t expand_groups(uint32_t ntiles);
-hipError_t launch_scan(const uint4 *meta, uint32_t *roff, uint32_t *totals, uint32_t ntiles,
+hipError_t launch_scan(const uint4 *meta, uint32_t *roff, uint64_t *totals /* [T] {total, epoch} */, uint32_t ntiles,
                        int nframes, uint32_t *offsets, uint32_t *ticket /* zero between launches */,
-                       hipStream_t s);
+                       uint32_t epoch /* != 0, different from the launch that last wrote `totals` */, hipStream_t s);
 hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s);
 
 // stream_ops.hip

@@ -1,9 +1,10 @@
-// pack_common.h -- device helpers shared by the diff/threshold/pack kernels (diff_pack.hip, diff_fused.hip):
+// pack_common.h -- device helpers of the diff/threshold/pack kernels (diff_pack.hip):
 // wave64 DPP scan, the 4-bytes-per-instruction compare / difference / feedback arithmetic, frame loads.
 #ifndef MI355_PACK_COMMON_H_
 #define MI355_PACK_COMMON_H_
 
 #include "internal.h"
+#include "lab.h"
 
 namespace mi355 {
 
@@ -132,9 +133,6 @@ __device__ __forceinline__ void store16_bytes(uint8_t *p, uint4 v, int valid) {
 // A stream's frames are read exactly once: non-temporal loads keep them from displacing the record
 // log and the meta words (written here, read back by k_expand) from the caches.  (Pair mode keeps
 // plain loads: callers often hand in overlapping cur/prev sequences that do hit.)
-#ifndef MI355_NT_LOADS
-#define MI355_NT_LOADS 1
-#endif
 template <bool FAST, bool NT = false>
 __device__ __forceinline__ uint4 load16(const uint8_t *p, int valid) {
     if (FAST) {
@@ -143,11 +141,7 @@ __device__ __forceinline__ uint4 load16(const uint8_t *p, int valid) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef const __attribute__((address_space(1))) u32x4 *gptr;
         const gptr g = (gptr)(uintptr_t)p;
-#if MI355_NT_LOADS
         const u32x4 v = NT ? __builtin_nontemporal_load(g) : *g;
-#else
-        const u32x4 v = *g;
-#endif
         return make_uint4(v.x, v.y, v.z, v.w);
     }
     return load16_bytes(p, valid);

@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MI355DIFF_LIB: another build of the same library (A/B builds under build/ab/, the EXPERIMENTS=1 build) for the tests
+# MI355DIFF_LIB: another build of the same library (the laboratory builds of tools/ab_build.sh under build/ab/)
 LIB_PATH = os.environ.get("MI355DIFF_LIB") or os.path.join(_HERE, "libmi355diff.so")
 
 OK = 0
@@ -21,9 +21,7 @@ VIS_NONE, VIS_HEAT, VIS_RED, VIS_RED_OVERLAP, VIS_GRAY, VIS_BINARIZE = range(6)
 (OP_GRAY_AVG, OP_GRAY_WEIGHTED, OP_BINARIZE, OP_GRAY_AVG_BINARIZE, OP_GRAY_WEIGHTED_BINARIZE, OP_HEAT_MAP,
  OP_RED_DENSE, OP_CONV3X3, OP_MEDIAN5X5) = range(1, 10)
 
-
-FLAG_FUSED = 1   # MI355_FLAG_FUSED: the one-kernel stream form (experiment, csrc/diff_fused.hip)
-FLAG_CHAIN = 2   # MI355_FLAG_CHAIN: the one-pass chained-scan pair form (experiment, csrc/diff_chain.hip)
+OPT_PIPELINE, OPT_SPLIT_PCT, OPT_DENSE_PCT, OPT_CHAIN_HINT, OPT_PACK_BLOCKS = range(1, 6)   # MI355_OPT_*
 
 
 class Config(C.Structure):
@@ -50,6 +48,8 @@ SYMBOLS = {
     "mi355_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi355_use_own_stream": (C.c_int, [C.c_void_p]),
     "mi355_synchronize": (C.c_int, [C.c_void_p]),
+    "mi355_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mi355_get_option": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "mi355_set_state": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi355_get_state": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi355_state_device_ptr": (C.c_void_p, [C.c_void_p]),
@@ -121,7 +121,7 @@ SYMBOLS = {
     "mi355_group_synchronize": (C.c_int, [C.c_void_p]),
 }
 GROUP_ID_BYTES = 128   # MI355_GROUP_ID_BYTES
-ABI_VERSION = 4        # MI355_ABI_VERSION of the include/mi355diff.h these argument lists were written against
+ABI_VERSION = 5        # MI355_ABI_VERSION of the include/mi355diff.h these argument lists were written against
 
 _lib = None
 

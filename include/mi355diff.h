@@ -51,30 +51,19 @@ typedef struct mi355_config {
     int32_t device;     /* HIP device ordinal, or -1 for the current device */
     int32_t noise_filter; /* != 0: exec() runs the 3x3 convolution first (NOISE_FILTER, common.h:5) */
     int32_t visualizer; /* MI355_VIS_* used by exec() (NOISE_VISUALIZER, common.h:11) */
-    int32_t flags;      /* MI355_FLAG_*; 0 = defaults */
+    int32_t flags;      /* reserved: must be 0 (no flag is defined; anything else is refused) */
 } mi355_config;
-
-/* The two flags below select EXPERIMENTS that are only in a library built with `make EXPERIMENTS=1`; the default
- * build refuses them (MI355_ERR_INVALID).  Both kernels wait for each other with bounded spins; a wait that expires
- * leaves the batch's output (and, for FUSED, the state) undefined and is reported ONLY by mi355_synchronize
- * (MI355_ERR_STATE; the core then falls back to the log path): a caller of the experiments synchronises with
- * mi355_synchronize, not through a stream of its own.  Thresholds 0..127 only.
- * Experiment, off by default: mi355_diff_stream_batch as ONE resident kernel instead of the three-kernel log
- * path, when the frame fits the device (every workgroup must be resident at once; 1080p fits).  Bit-exact with
- * the log path and slower on the MI355X (csrc/diff_fused.hip says why).  Also MI355_FUSED=1 in the environment. */
-#define MI355_FLAG_FUSED 1
-/* Experiment, off by default: mi355_diff_pairs_batch as ONE pass with a chained scan (decoupled look-back)
- * instead of the three-kernel log path; bit-exact, on the MI355X as fast on dense pairs and slower on sparse
- * ones (csrc/diff_chain.hip says why).  Also MI355_CHAIN=1 in the environment. */
-#define MI355_FLAG_CHAIN 2
 
 /* ABI version of this header: bumped whenever an existing entry point changes its argument list (round 3 did that to
  * mi355_group_gather without a marker: a caller built against the older header still linked and passed shifted
  * arguments).  A binding checks mi355_abi_version() == MI355_ABI_VERSION when it loads the library
  * (cudavideostream_amd/lib.py, compat/include/group.hpp do).
  *   3  round 3: mi355_group_gather gained member_capacity (6th argument)
- *   4  round 4: + mi355_abi_version, mi355_probe_clock, mi355_probe_hbm_read (additions only) */
-#define MI355_ABI_VERSION 4
+ *   4  round 4: + mi355_abi_version, mi355_probe_clock, mi355_probe_hbm_read (additions only)
+ *   5  round 5: + mi355_set_option / mi355_get_option; MI355_FLAG_FUSED / MI355_FLAG_CHAIN (two opt-in experiments) are
+ *      gone and cfg.flags must be 0; the environment variables MI355_SPLIT, MI355_DENSE_PCT, MI355_CHAIN_HINT and the
+ *      undocumented tuning variables are no longer read (options below) */
+#define MI355_ABI_VERSION 5
 int mi355_abi_version(void);
 
 /* ---- life cycle: CUDACore::CUDACore (kernels.cu:377-428) without the uploads ------------------ */
@@ -102,6 +91,27 @@ size_t mi355_workspace_bytes(const mi355_core *core);
 int mi355_set_stream(mi355_core *core, void *hip_stream);
 int mi355_use_own_stream(mi355_core *core);
 int mi355_synchronize(mi355_core *core);
+/* Lifetime of the caller's buffers.  The device-resident entry points are asynchronous: every d_ buffer handed to one
+ * (inputs AND outputs) must stay allocated, and the inputs unmodified, until the work has completed -- mi355_synchronize,
+ * or, with mi355_set_stream, the caller's own synchronisation of that stream.  A framework whose allocator recycles a
+ * freed tensor for other kernels on ITS stream (PyTorch's caching allocator) must keep the tensors referenced until
+ * then: on the core's own stream the library's kernels are not ordered against the framework's stream.
+ * (cudavideostream_amd/core.py holds such references itself until synchronize().) */
+
+/* Options.  The schedule of the batches on the core's own stream can be tuned per core; RESULTS never depend on it.
+ * Changing an option first waits for the work the core has queued.  The library reads exactly ONE environment
+ * variable: MI355_PIPELINE=0 makes MI355_OPT_PIPELINE default to 0 for every core of the process (a switch for the
+ * operator of an unmodified server binary); nothing else in the environment steers it. */
+#define MI355_OPT_PIPELINE 1     /* 1 (default): own-stream batches are pipelined (below); 0: one kernel after the other */
+#define MI355_OPT_SPLIT_PCT 2    /* 50 (default): a pipelined batch is packed by two launches, this share of the tiles on
+                                  * the first; 5..95, or 0 = one launch */
+#define MI355_OPT_DENSE_PCT 3    /* 40 (default): batches in which more than this share of the bytes changed are not
+                                  * overlapped (adaptive overlap, below); 0 = always overlap, 100 = same */
+#define MI355_OPT_CHAIN_HINT 4   /* 1 (default): a batch that follows a frame filter on this core is not overlapped; 0: is */
+#define MI355_OPT_PACK_BLOCKS 5  /* -1 (default): the pipelined pack kernel runs on 4 workgroups per CU; 0: one tile per
+                                  * wave; n > 0: n workgroups */
+int mi355_set_option(mi355_core *core, int option, int value);
+int mi355_get_option(mi355_core *core, int option, int *value);
 
 /* ---- state: the reconstructed client frame ("previous" with negative feedback) ------------------
  * kernels.cu:406 uploads the base frame into d_current; after each frame the surviving buffer is
@@ -136,12 +146,12 @@ int mi355_set_glyphs(mi355_core *core, const uint8_t *chars_px, int nglyphs, int
  * mi355_int_diff) take frames, not packed streams, and are ordered on the core's stream only: they may run beside
  * the expansion of the batch before (visualiser of frame k + 1 beside the expansion of frame k).  With a caller's
  * stream (mi355_set_stream) nothing is pipelined: every kernel runs on that stream, in call order.
- * MI355_PIPELINE=0 in the environment switches the pipelining off.  (A pipelined batch is packed by two kernel launches
- * on two streams of the core, half the tiles each; MI355_SPLIT=0 packs it with one.)
+ * MI355_OPT_PIPELINE 0 (or MI355_PIPELINE=0 in the environment) switches the pipelining off.  (A pipelined batch is packed
+ * by two kernel launches on two streams of the core, half the tiles each; MI355_OPT_SPLIT_PCT 0 packs it with one.)
  * A batch that follows a frame filter on this core (the server's visualiser or noise filter in front of every diff) is not
- * overlapped either: one kernel after the other measured faster for such chains (MI355_CHAIN_HINT=0 when the core is
- * created: overlap regardless).
- * The overlap is adaptive: a batch in which more than 40 % of the bytes changed (a scene change; MI355_DENSE_PCT) has an
+ * overlapped either: one kernel after the other measured faster for such chains (MI355_OPT_CHAIN_HINT 0: overlap
+ * regardless).
+ * The overlap is adaptive: a batch in which more than 40 % of the bytes changed (a scene change; MI355_OPT_DENSE_PCT) has an
  * expansion longer than its pack kernel and loses by running beside the next batch.  The library copies every own-stream
  * batch's total to pinned host memory behind its expansion and, without ever waiting for it, runs batches one after the
  * other while the latest total that has arrived says "dense".  Only the schedule depends on it, never a result.
@@ -352,7 +362,9 @@ int mi355_group_synchronize(mi355_group *group);
  * ms_pack = the diff/threshold/pack kernel alone, ms_total = pack + scan + gather. */
 int mi355_set_timing(mi355_core *core, int enabled);
 int mi355_get_timing(mi355_core *core, double *ms_pack, double *ms_total, int *launches);
-/* The same sums per kernel: pack (k_diff_pack), scan (k_scan_groups), expand (k_expand); their sum is ms_total. */
+/* The same sums per kernel: pack (k_diff_pack; both launches of a split pipelined batch, from the start of the first to
+ * the end of whichever ends later), scan (k_scan_groups), expand (k_expand).  One batch after the other their sum is
+ * ms_total; pipelined batches wait between their pack kernel and their index (for the stream hop), so ms_total is larger. */
 int mi355_get_kernel_timing(mi355_core *core, double *ms_pack, double *ms_scan, double *ms_expand, int *launches);
 int mi355_reset_timing(mi355_core *core);
 /* Diagnostics: the shader clock (MHz) the device holds under an integer-VALU load of about `milliseconds` ms

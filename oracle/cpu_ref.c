@@ -136,6 +136,107 @@ int ora_diff_stream(const uint8_t *frames, int nframes, uint8_t *state, size_t n
     return 0;
 }
 
+/* The all-cores form of the baseline (bench.py, cpu_baseline.all_cores): the batch's frames through the SAME loop
+ * (test.cu:560-576), a row band of the frame per thread for ALL frames of the batch -- a band's state belongs to its
+ * thread, so the threads never meet between frames (ora_diff_pack_mt starts its threads anew for every frame) --
+ * then the bands' pieces are put together in (frame, band) order, which is the ascending order of the whole frame:
+ * output identical to ora_diff_stream (tests/test_oracle.py).  nthreads: 1..1024. */
+struct stream_job {
+    const uint8_t *frames; uint8_t *state;
+    size_t n, lo, hi;
+    int nframes, thr;
+    int32_t *sxs; uint8_t *sdf;     /* the band's scratch: (hi - lo) * nframes entries at most */
+    uint32_t *counts;               /* [nframes] entries of the band per frame */
+    /* second phase */
+    const size_t *dst;              /* [nframes] where the band's piece of frame f goes */
+    int32_t *xs; uint8_t *diff;
+    int failed;
+};
+
+static void *stream_pack_worker(void *p) {
+    struct stream_job *j = (struct stream_job *)p;
+    size_t pos = 0;
+    for (int f = 0; f < j->nframes; f++) {
+        const uint8_t *cur = j->frames + (size_t)f * j->n;
+        const size_t first = pos;
+        for (size_t i = j->lo; i < j->hi; i++) {
+            int df = (int)cur[i] - (int)j->state[i];
+            if (df < -j->thr || df > j->thr) {
+                j->sdf[pos] = (uint8_t)df;
+                j->sxs[pos] = (int32_t)i;
+                pos++;
+                j->state[i] = cur[i];
+            }
+        }
+        j->counts[f] = (uint32_t)(pos - first);
+    }
+    return NULL;
+}
+
+static void *stream_place_worker(void *p) {
+    struct stream_job *j = (struct stream_job *)p;
+    size_t pos = 0;
+    for (int f = 0; f < j->nframes; f++) {
+        memcpy(j->xs + j->dst[f], j->sxs + pos, (size_t)j->counts[f] * sizeof *j->xs);
+        memcpy(j->diff + j->dst[f], j->sdf + pos, j->counts[f]);
+        pos += j->counts[f];
+    }
+    return NULL;
+}
+
+int ora_diff_stream_mt(const uint8_t *frames, int nframes, uint8_t *state, size_t n, int thr,
+                       uint32_t *offsets, int32_t *xs, uint8_t *diff, size_t cap, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 1024) nthreads = 1024;
+    if (nframes < 0) return -2;
+    struct stream_job *jobs = (struct stream_job *)calloc((size_t)nthreads, sizeof *jobs);
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof *th);
+    size_t *dst = (size_t *)calloc((size_t)nthreads * (size_t)(nframes ? nframes : 1), sizeof *dst);
+    int rc = (jobs && th && dst) ? 0 : -2;
+    const size_t per = (n + (size_t)nthreads - 1) / (size_t)nthreads;
+    for (int t = 0; t < nthreads && rc == 0; t++) {
+        struct stream_job *j = &jobs[t];
+        j->frames = frames; j->state = state; j->n = n; j->nframes = nframes; j->thr = thr;
+        j->lo = (size_t)t * per < n ? (size_t)t * per : n;
+        j->hi = j->lo + per < n ? j->lo + per : n;
+        const size_t room = (j->hi - j->lo) * (size_t)nframes + 1;   /* untouched pages cost nothing */
+        j->sxs = (int32_t *)malloc(room * sizeof *j->sxs);
+        j->sdf = (uint8_t *)malloc(room);
+        j->counts = (uint32_t *)calloc((size_t)nframes + 1, sizeof *j->counts);
+        j->dst = dst + (size_t)t * (size_t)(nframes ? nframes : 1);
+        j->xs = xs; j->diff = diff;
+        if (!j->sxs || !j->sdf || !j->counts) rc = -2;
+    }
+    if (rc == 0) {
+        int started = 0;
+        for (; started < nthreads; started++)
+            if (pthread_create(&th[started], NULL, stream_pack_worker, &jobs[started]) != 0) { rc = -2; break; }
+        for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    }
+    if (rc == 0) {   /* where every (frame, band) piece goes: frame-major, bands in order */
+        size_t off = 0;
+        offsets[0] = 0;
+        for (int f = 0; f < nframes; f++) {
+            for (int t = 0; t < nthreads; t++) {
+                dst[(size_t)t * (size_t)nframes + (size_t)f] = off;
+                off += jobs[t].counts[f];
+            }
+            offsets[f + 1] = (uint32_t)off;
+        }
+        if (off > cap) rc = -1;
+    }
+    if (rc == 0) {
+        int started = 0;
+        for (; started < nthreads; started++)
+            if (pthread_create(&th[started], NULL, stream_place_worker, &jobs[started]) != 0) { rc = -2; break; }
+        for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    }
+    if (jobs)
+        for (int t = 0; t < nthreads; t++) { free(jobs[t].sxs); free(jobs[t].sdf); free(jobs[t].counts); }
+    free(jobs); free(th); free(dst);
+    return rc;
+}
+
 /* client/opencv.cpp:64-66 */
 void ora_client_apply(uint8_t *frame, const int32_t *xs, const uint8_t *diff, uint32_t n) {
     for (uint32_t i = 0; i < n; i++) frame[xs[i]] += diff[i];

@@ -41,6 +41,10 @@ uint32_t ora_diff_pack_mt(const uint8_t *cur, uint8_t *state, size_t n, int thr,
  * Returns 0, or -1 if cap is too small. */
 int ora_diff_stream(const uint8_t *frames, int nframes, uint8_t *state, size_t n, int thr,
                     uint32_t *offsets, int32_t *xs, uint8_t *diff, size_t cap);
+/* the same over all host cores: a row band per thread for all frames of the batch; identical output (bench.py's
+ * cpu_baseline.all_cores).  0 ok, -1 cap too small, -2 out of memory / threads. */
+int ora_diff_stream_mt(const uint8_t *frames, int nframes, uint8_t *state, size_t n, int thr,
+                       uint32_t *offsets, int32_t *xs, uint8_t *diff, size_t cap, int nthreads);
 
 /* client/opencv.cpp:64-66: frame[xs[i]] += diff[i] (uint8 wrap). */
 void ora_client_apply(uint8_t *frame, const int32_t *xs, const uint8_t *diff, uint32_t n);

@@ -27,7 +27,8 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = os.path.join(_HERE, "liboracle.so")
+    # ORACLE_LIB: another build of the same file (the ASan/UBSan build of tests/sanitize.sh)
+    path = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
     if not os.path.exists(path):
         build()
     L = C.CDLL(path)
@@ -40,6 +41,8 @@ def lib():
     L.ora_diff_stream.restype = C.c_int
     L.ora_diff_stream.argtypes = [u8p, C.c_int, u8p, C.c_size_t, C.c_int, u32p, i32p, u8p,
                                   C.c_size_t]
+    L.ora_diff_stream_mt.restype = C.c_int
+    L.ora_diff_stream_mt.argtypes = [u8p, C.c_int, u8p, C.c_size_t, C.c_int, u32p, i32p, u8p, C.c_size_t, C.c_int]
     L.ora_client_apply.restype = None
     L.ora_client_apply.argtypes = [u8p, i32p, u8p, C.c_uint32]
     L.ora_generate_image.restype = None
@@ -124,6 +127,21 @@ def diff_stream(frames, state, thr=20):
     df = np.empty(max(cap, 1), np.uint8)
     rc = lib().ora_diff_stream(frames.reshape(-1), T, st, n, thr, offsets, xs, df, cap)
     assert rc == 0
+    tot = int(offsets[-1])
+    return offsets, xs[:tot].copy(), df[:tot].copy(), st
+
+
+def diff_stream_mt(frames, state, thr=20, nthreads=8, cap=None):
+    """diff_stream over `nthreads` host threads (a row band per thread for all frames): identical output."""
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    T, n = frames.shape
+    st = _u8(state).copy()
+    cap = T * n if cap is None else cap
+    offsets = np.zeros(T + 1, np.uint32)
+    xs = np.empty(max(cap, 1), np.int32)
+    df = np.empty(max(cap, 1), np.uint8)
+    rc = lib().ora_diff_stream_mt(frames.reshape(-1), T, st, n, thr, offsets, xs, df, cap, nthreads)
+    assert rc == 0, rc
     tot = int(offsets[-1])
     return offsets, xs[:tot].copy(), df[:tot].copy(), st
 

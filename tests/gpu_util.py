@@ -24,10 +24,8 @@ def _synced(name):
 
     def call(self, *args, **kwargs):
         torch.cuda.synchronize()
-        # the call is asynchronous on the core's stream: tensors handed in as temporaries (core.conv3x3(to_dev(a), out))
-        # must outlive it, or torch's allocator gives their memory to the next to_dev() while the kernel still reads it
-        keep = self.__dict__.setdefault("_keepalive", [])
-        keep.extend(a for a in list(args) + list(kwargs.values()) if torch.is_tensor(a))
+        # (temporaries handed in -- core.conv3x3(to_dev(a), out) -- are kept alive by the product class itself until
+        # synchronize(): cudavideostream_amd/core.py, _hold)
         return inner(self, *args, **kwargs)
 
     call.__name__ = name
@@ -37,14 +35,6 @@ def _synced(name):
 
 for _name in _DEVICE_CALLS:
     setattr(CUDACore, _name, _synced(_name))
-
-
-def _synchronize(self):
-    _CUDACore.synchronize(self)
-    self.__dict__.pop("_keepalive", None)
-
-
-CUDACore.synchronize = _synchronize
 
 
 def to_dev(a):

@@ -486,14 +486,11 @@ def test_filter_then_diff_on_own_stream_orders_every_part(po):
     filt = torch.empty((T, n), dtype=torch.uint8, device=DEV)
     outs = [(torch.zeros(T + 1, dtype=torch.int32, device=DEV), torch.full((T * n,), -7, dtype=torch.int32, device=DEV),
              torch.zeros(T * n, dtype=torch.uint8, device=DEV)) for _ in range(K)]
-    # (MI355_CHAIN_HINT=0, read when a core is created: by default a batch that follows a frame filter is not overlapped at
-    # all -- this test is about the overlapped batch's ordering)
-    os.environ["MI355_CHAIN_HINT"] = "0"
-    try:
-        core_cm = CUDACore(w, h, k=k9, max_batch=T, sample_mat_data=base)
-    finally:
-        del os.environ["MI355_CHAIN_HINT"]
-    with core_cm as core:
+    # (MI355_OPT_CHAIN_HINT 0: by default a batch that follows a frame filter is not overlapped at all -- this test is about
+    # the overlapped batch's ordering)
+    with CUDACore(w, h, k=k9, max_batch=T, sample_mat_data=base) as core:
+        core.set_option(lib.OPT_CHAIN_HINT, 0)
+        assert core.get_option(lib.OPT_CHAIN_HINT) == 0
         torch.cuda.synchronize()
         for k in range(K):
             RawCore.filter_batch(core, lib.OP_CONV3X3, d_fr[k * T:(k + 1) * T], filt, T)

@@ -207,6 +207,30 @@ def test_mt_matches_single_thread(po):
             assert np.array_equal(a, b)
 
 
+def test_stream_mt_matches_single_thread(po):
+    """bench.py's all-cores baseline (ora_diff_stream_mt: a row band per thread for all frames of the batch) produces
+    the single-threaded stream bit for bit: offsets, entries, final state -- also with more threads than bytes, empty
+    batches, a capacity that is too small."""
+    rng = np.random.default_rng(16)
+    n, T = 30011, 7
+    base = rng.integers(0, 256, n, dtype=np.uint8)
+    frames = np.clip(base.astype(int)[None, :] + rng.integers(-30, 31, (T, n)), 0, 255).astype(np.uint8)
+    ref = po.diff_stream(frames, base)
+    for nt in (1, 2, 5, 8, 64, 1024):
+        got = po.diff_stream_mt(frames, base, nthreads=nt)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), nt
+    tiny = po.diff_stream_mt(frames[:, :3], base[:3], nthreads=8)
+    for a, b in zip(tiny, po.diff_stream(frames[:, :3], base[:3])):
+        assert np.array_equal(a, b)
+    off, xs, df, st = po.diff_stream_mt(frames[:0], base, nthreads=4)
+    assert off.tolist() == [0] and xs.size == 0 and np.array_equal(st, base)
+    L = po.lib()
+    o = np.zeros(T + 1, np.uint32)
+    rc = L.ora_diff_stream_mt(frames.reshape(-1), T, base.copy(), n, 20, o, np.empty(8, np.int32), np.empty(8, np.uint8), 8, 4)
+    assert rc == -1
+
+
 # ---- semantics at the threshold -------------------------------------------------------------------
 
 def test_edge_strip_threshold_semantics(po):

@@ -1,0 +1,76 @@
+"""The N > 1 job exactly as the driver starts it -- `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`:
+one PROCESS per rank, mi355_group_adopt_rank with an id made by rank 0 and handed around by torch.distributed, the timed
+steps, mi355_group_gather inside the timed region, the gather-every-batch leg -- on the ONE GPU of a test box:
+`--rehearse-on-one-gpu` puts every rank on device 0, torch.distributed on gloo and the exchange below the C-ABI on the
+tests' inter-process stand-in for RCCL (tests/mock_rccl/mock_rccl_ipc.cpp; real RCCL refuses two ranks on one device).
+What it cannot show is RCCL's own transport; everything else of bench.py's N > 1 path runs.  The line's `gather_verified`
+says that the root holds, for every rank, the entries that rank produced."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MOCK = os.path.join(ROOT, "tests", "mock_rccl", "librccl_mock_ipc.so")
+SMALL = ["--width", "640", "--height", "360", "--batch", "8", "--steps", "3", "--warmup", "2", "--gather-every-steps", "2",
+         "--no-cpu", "--no-pair", "--no-filters", "--no-host-path", "--no-config5"]
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(extra, env=None, timeout=420):
+    e = dict(os.environ, MOCK_RCCL_TIMEOUT_S="60")
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, cwd=ROOT, env=e, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=timeout)
+    lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.skipif(not os.path.exists(MOCK), reason="tests/mock_rccl/librccl_mock_ipc.so not built (__graft_entry__.build())")
+@pytest.mark.parametrize("shard", ["streams", "roundrobin"])
+def test_two_processes_run_the_bench_sequence(shard):
+    r, line = run_bench(["--gpus", "2", "--rehearse-on-one-gpu", "--shard", shard] + SMALL)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    assert line is not None and line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    assert "rehearsal" in line and "REHEARSAL" in line["config"]["gather_impl"]
+    assert line["gather_verified"] is True
+    assert line["gather_ms"] > 0 and line["gather_bytes"] > 4 * 9 * 2
+    ge = line["gather_every"]
+    assert ge["steps"] == 2 and ge["gather_bytes"] > 0 and ge["value"] > 0
+    assert line["value"] > 0 and line["steps"] == 3 and line["scaling"] == "weak"
+
+
+@pytest.mark.skipif(not os.path.exists(MOCK), reason="tests/mock_rccl/librccl_mock_ipc.so not built")
+def test_three_processes_and_a_rank_that_cannot_form_the_group():
+    """Three ranks; then the same job with a library that cannot be loaded on the ranks: every rank says which step failed
+    and the job ends with exit status 3 instead of hanging or measuring something else."""
+    r, line = run_bench(["--gpus", "3", "--rehearse-on-one-gpu"] + SMALL)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    assert line["ranks_seen"] == 3 and line["gather_verified"] is True
+    r, line = run_bench(["--gpus", "2", "--rehearse-on-one-gpu"] + SMALL, env={"MI355_RCCL_LIB": "/nonexistent/librccl.so"})
+    err = r.stderr.decode(errors="replace")
+    assert r.returncode != 0 and line is None
+    assert "forming the group failed in mi355_group_unique_id" in err and "MI355_RCCL_LIB" in err
+    assert "rank 1 of 2" in err or "rank 0 of 2" in err
+
+
+def test_one_rank_under_the_launcher_reports_the_gather():
+    """N = 1 the way the driver could start it (torch.distributed.run, real RCCL, one rank): the line carries ranks_seen,
+    gather_ms and gather_bytes of the same code path the N > 1 runs take."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, r.stderr.decode(errors="replace")[-3000:]
+    line = json.loads(lines[-1])
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["gather_verified"] is True
+    assert line["gather_ms"] is not None and line["gather_bytes"] > 0
+    assert "RCCL" in line["config"]["gather_impl"] and "rehearsal" not in line

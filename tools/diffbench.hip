@@ -7,6 +7,8 @@
 //
 //   diffbench [--width W] [--height H] [--batch B] [--steps K] [--warmup W] [--seed S]
 //             [--pairs] [--checksum T] [--cores C] [--digest]
+//             [--opt ID=VALUE ...]      mi355_set_option on every core (1 pipeline, 2 split per cent, 3 dense per cent,
+//                                       4 chain hint, 5 pack workgroups: include/mi355diff.h "Options")
 //   diffbench --filters [--batch B] [--steps K]     the filter kernels and the BASELINE config 3 / 4 chains
 //                                                   (same lines as tools/bench_filters.py, for the --pmc passes)
 #include <hip/hip_runtime.h>
@@ -17,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "../include/mi355diff.h"
@@ -89,6 +92,7 @@ int main(int argc, char **argv) {
     uint32_t seed = 21;
     bool pairs = false, filters = false, digest = false, apart = false;
     const char *corun = nullptr; int corun_blocks = 2048;
+    std::vector<std::pair<int, int>> opts;
     const char *regime = nullptr;   // --regime s0|flip|static: pairs of the dense / static regimes (tools/bench_regimes.py's inputs)
     for (int i = 1; i < argc; i++) {
         auto next = [&](int &v) { if (i + 1 < argc) v = atoi(argv[++i]); };
@@ -107,7 +111,9 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--corun") && i + 1 < argc) corun = argv[++i];
         else if (!strcmp(argv[i], "--regime") && i + 1 < argc) { regime = argv[++i]; pairs = true; }
         else if (!strcmp(argv[i], "--corun-blocks")) next(corun_blocks);
+        else if (!strcmp(argv[i], "--opt") && i + 1 < argc) { int id = 0, v = 0; if (sscanf(argv[++i], "%d=%d", &id, &v) == 2) opts.push_back({id, v}); }
     }
+    auto apply_opts = [&](mi355_core *c) { for (auto &o : opts) MI_OK(mi355_set_option(c, o.first, o.second)); };
     const size_t n = (size_t)3 * W * H;
     if (checksum_t >= -1) {  // print a checksum of one generated frame (generator cross-check)
         uint8_t *d; HIP_OK(hipMalloc((void **)&d, n));
@@ -133,6 +139,7 @@ int main(int argc, char **argv) {
         std::vector<uint8_t> h_base(n);
         for (int c = 0; c < ncores; c++) {
             MI_OK(mi355_create(&cfg, &cores[c]));
+            apply_opts(cores[c]);
             HIP_OK(hipMalloc((void **)&fr[c], n * (size_t)(B + 1)));
             for (int t = -1; t < B; t++)
                 hipLaunchKernelGGL(k_webcam_frame, g, b, 0, 0, fr[c] + (size_t)(t + 1) * n, t, W, H, seed + c);
@@ -162,6 +169,7 @@ int main(int argc, char **argv) {
     if (filters) {   // mi355_filter_batch per kernel, then the two chains; B frames resident, K repetitions each
         mi355_core *core = nullptr;
         MI_OK(mi355_create(&cfg, &core));
+        apply_opts(core);
         uint8_t *fr, *out, *filt; uint32_t *off; int32_t *xs; uint8_t *df;
         const size_t cap = (size_t)B * n / 4;
         HIP_OK(hipMalloc((void **)&fr, n * (size_t)(B + 1)));
@@ -214,6 +222,7 @@ int main(int argc, char **argv) {
     }
     mi355_core *core = nullptr;
     MI_OK(mi355_create(&cfg, &core));
+    apply_opts(core);
 
     uint8_t *d_frames = nullptr, *d_base = nullptr;
     const int nfr = apart ? 2 * B : B + 1;
