@@ -466,24 +466,38 @@ def main():
     if dist is not None and args.gather != "none":
         gather_impl = ("mi355_group_gather (csrc/group.hip) over the tests' inter-process stand-in for RCCL: REHEARSAL"
                        if rehearse else "mi355_group_gather (RCCL, csrc/group.hip)")
-        stage = "mi355_group_unique_id"
-        try:
-            from cudavideostream_amd.group import CUDAGroup, unique_id
-            ident = torch.from_numpy(unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(cdev)
-            stage = "torch.distributed broadcast of the id"
-            dist.broadcast(ident, src=0)
+        # Every rank takes part in every collective of this block whatever happened to it before: a rank that raised and
+        # skipped a broadcast would leave the others waiting in it (torch.distributed's timeout is half an hour).
+        stage, err = "mi355_group_unique_id", None
+        ident = np.zeros(1 + 128, np.uint8)          # [0] = 1: rank 0 made the id
+        if rank == 0:
+            try:
+                from cudavideostream_amd.group import unique_id
+                ident[1:] = unique_id()
+                ident[0] = 1
+            except Exception as e:   # noqa: BLE001
+                err = e
+        t_id = torch.from_numpy(ident).to(cdev)
+        dist.broadcast(t_id, src=0)
+        ident = t_id.cpu().numpy()
+        if err is None and ident[0] != 1:
+            stage, err = "mi355_group_unique_id on rank 0", RuntimeError("rank 0 could not make the group's id")
+        if err is None:
             stage = "mi355_group_adopt_rank"
-            group = CUDAGroup.adopt(core, world, rank, ident.cpu().numpy())
-            root_cap = world * cap if rank == 0 else 0
-            r_off = torch.zeros((world, B + 1), dtype=torch.int32, device=dev) if rank == 0 else None
-            r_xs = torch.empty(root_cap, dtype=torch.int32, device=dev) if rank == 0 else None
-            r_df = torch.empty(root_cap, dtype=torch.uint8, device=dev) if rank == 0 else None
-        except Exception as e:   # noqa: BLE001
-            group = None
-            gather_impl = f"torch.distributed (mi355_group unavailable: {repr(e)[:100]})"
+            try:
+                from cudavideostream_amd.group import CUDAGroup
+                group = CUDAGroup.adopt(core, world, rank, ident[1:])
+                root_cap = world * cap if rank == 0 else 0
+                r_off = torch.zeros((world, B + 1), dtype=torch.int32, device=dev) if rank == 0 else None
+                r_xs = torch.empty(root_cap, dtype=torch.int32, device=dev) if rank == 0 else None
+                r_df = torch.empty(root_cap, dtype=torch.uint8, device=dev) if rank == 0 else None
+            except Exception as e:   # noqa: BLE001
+                group, err = None, e
+        if err is not None:
+            gather_impl = f"torch.distributed (mi355_group unavailable: {repr(err)[:100]})"
             # WHICH step failed, on WHICH rank, with the library's own text (it names the RCCL entry point:
             # csrc/group.hip RCCL_TRY) -- before anything else happens to this process
-            print(f"bench.py: rank {rank} of {world} (device {local_rank}): forming the group failed in {stage}: {e!r}",
+            print(f"bench.py: rank {rank} of {world} (device {local_rank}): forming the group failed in {stage}: {err!r}",
                   file=sys.stderr, flush=True)
         ok = torch.tensor([1 if group is not None else 0], device=cdev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank takes the same way

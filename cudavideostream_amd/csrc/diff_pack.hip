@@ -55,6 +55,7 @@ static_assert(kStreamPrefetch % 2 == 0, "frames are processed in pairs");
 //         bits 16..23  ONE flagged byte: its difference;  more: the lane's rank among the tile's
 //                      multi-byte lanes of this frame (where its record is)
 //         bits 24..29  the lane
+//         bits 30..31  the tile modulo 4 (which tile of a round's quad or pair the expander's lane is looking at)
 //   * one 16-byte RECORD (the 16 masked difference bytes) per lane with >= 2 flagged bytes,
 //   * one 16-byte meta word {byte offset of the frame's first code, of its first record, flagged bytes,
 //     candidates | multi-byte lanes << 16}.
@@ -217,7 +218,7 @@ __device__ __forceinline__ void pack_group(const PackArgs &a, const Group<PAIR, 
     // The group's kPrefetch meta words are assembled in lanes 0..kPrefetch-1 and leave with ONE store.
     constexpr int kPrefetch = PrefetchOf<PAIR>::value;
     uint4 meta = make_uint4(0, 0, 0, 0);
-    const uint32_t lane24 = (uint32_t)lane << 24;
+    const uint32_t lane24 = ((uint32_t)lane << 24) | (tile << 30);   // bits 30..31 of a code: its tile modulo 4 (expand_group)
     const uint32_t jump = (a.ntiles - 1u) * 1024u;
 #pragma unroll
     for (int d = 0; d < kPrefetch; d += 2) {
@@ -523,7 +524,7 @@ hipError_t launch_scan(const uint4 *meta, uint32_t *roff, uint64_t *totals, uint
 // ---- expand: codes + records -> packed frame-major (xs, diff) ------------------------------------------
 // grid = (ceil(W/16), T) single-wave workgroups: a wave owns one ITEM = 16 consecutive tiles of ONE frame, i.e. one
 // contiguous range of that frame's output (the scan kernel gives the entries in front of it).  Two ways through an item:
-//   * the pair path (expand_pairs): items whose neighbouring tiles 2r, 2r + 1 have at most 64 candidates together,
+//   * the group path (expand_group<4> / <2>): items whose neighbouring four (or two) tiles have at most 64 candidates together,
 //     whose entries fit the LDS stage at once and which have at most 128 lanes with two or more flagged bytes -- all
 //     items of a webcam-like frame outside dense regions.  Round r expands tiles 2r and 2r + 1: the candidates of the
 //     first in lanes 0 .. nc - 1, those of the second behind them, so a lane finds its tile with one compare.  The 8
@@ -691,37 +692,52 @@ __device__ __forceinline__ void walk_records(uint32_t m16, uint32_t e, uint32_t 
     }
 }
 
-// The pair path.  mx / my / mz hold, in lane L < 16, tile L's {byte offset of its first code, byte offset of its first
-// record, entries of the item before the tile | candidates << 16}.  What a round needs of its two tiles is wave-uniform
-// and is read into SGPRs (v_readlane) right where it is used: through LDS the same facts cost a write, a read and a
-// wait per round (~150 cycles each; a third of the wave's lifetime, profiles/r04l_expand_stamps.log).
+// The group path.  mx / my / mz hold, in lane L < 16, tile L's {byte offset of its first code, byte offset of its first
+// record, entries of the item before the tile | candidates << 16}.  Round r expands the G consecutive tiles G r .. G r + G - 1
+// (G = 4: "quads", G = 2: "pairs"), whose candidates together fill at most the 64 lanes: those of the first tile in lanes
+// 0 .. nc0 - 1, those of the next behind them, and so on.  What a round needs of its tiles is wave-uniform and is read into
+// SGPRs (v_readlane) right where it is used: through LDS the same facts cost a write, a read and a wait per round (~150
+// cycles each; a third of the wave's lifetime, profiles/r04l_expand_stamps.log).  Which tile of the group a candidate
+// belongs to is written in its code (bits 30..31 = tile & 3, k_diff_pack): only the LOAD of the codes has to find a lane's
+// tile from the counts (G - 1 compares).  A candidate's place in the output needs no tile at all: the tiles of a group
+// are neighbours in the output too, so it is the entries in front of the group plus the wave-wide scan of the round.
+// Round 5: quads.  On webcam-like input a tile holds ~12 candidates (isolated bytes): a pair of tiles used 24 of a
+// round's 64 lanes, a quad uses 48 -- half the rounds for the same item (profiles/r05_*).
 // Fills stage[0 .. entries of the item) in output order.
-__device__ __forceinline__ void expand_pairs(const ExpandArgs &a, uint32_t mx, uint32_t my, uint32_t mz, uint2 *list, uint32_t *stage,
+template <int G>
+__device__ __forceinline__ void expand_group(const ExpandArgs &a, uint32_t mx, uint32_t my, uint32_t mz, uint2 *list, uint32_t *stage,
                                              uint32_t lane) {
+    static_assert(G == 2 || G == 4, "a code names its tile modulo 4");
+    constexpr uint32_t R = kWTiles / G;
     const __amdgpu_buffer_rsrc_t codes = make_rsrc(a.codes, a.codes_bytes), recs = make_rsrc(a.rec, a.rec_bytes);
-    // round r: the candidates of tile 2r in lanes 0 .. nc - 1, those of tile 2r + 1 behind them (together at most 64)
-    uint32_t code[kWTiles / 2];
+    uint32_t code[R];
     const uint32_t lane4 = lane * 4u;
 #pragma unroll
-    for (uint32_t r = 0; r < kWTiles / 2; r++) {
-        const uint32_t nc_a = (uint32_t)__builtin_amdgcn_readlane((int)mz, 2 * r) >> 16, nc_b = (uint32_t)__builtin_amdgcn_readlane((int)mz, 2 * r + 1) >> 16;
-        const uint32_t pc_a = (uint32_t)__builtin_amdgcn_readlane((int)mx, 2 * r), pc_b = (uint32_t)__builtin_amdgcn_readlane((int)mx, 2 * r + 1);
-        const uint32_t off = lane >= nc_a ? lane4 + (pc_b - 4u * nc_a) : lane4 + pc_a;
-        code[r] = __builtin_amdgcn_raw_buffer_load_b32(codes, lane < nc_a + nc_b ? off : kOOB, 0, 0);   // a lane without a candidate reads 0
+    for (uint32_t r = 0; r < R; r++) {
+        // lane L < t1: code L of the first tile; t1 <= L < t2: code L - t1 of the second; ... (t = running candidate count)
+        uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)mz, G * r) >> 16;
+        uint32_t sel = (uint32_t)__builtin_amdgcn_readlane((int)mx, G * r);
+#pragma unroll
+        for (uint32_t k = 1; k < G; k++) {
+            const uint32_t pc = (uint32_t)__builtin_amdgcn_readlane((int)mx, G * r + k);
+            sel = lane >= t ? pc - 4u * t : sel;
+            t += (uint32_t)__builtin_amdgcn_readlane((int)mz, G * r + k) >> 16;
+        }
+        code[r] = __builtin_amdgcn_raw_buffer_load_b32(codes, lane < t ? lane4 + sel : kOOB, 0, 0);   // a lane without a candidate reads 0
     }
     if (kXAblate == 2) {   // lab: prologue + code loads
         uint32_t acc = 0;
 #pragma unroll
-        for (uint32_t r = 0; r < kWTiles / 2; r++) acc ^= code[r];
+        for (uint32_t r = 0; r < R; r++) acc ^= code[r];
         if (acc == 0xfffffff0u) stage[0] = acc;
         return;
     }
-    __builtin_amdgcn_sched_barrier(0);   // all eight requests leave before anything waits for the first
-    // entry offsets of all rounds first: eight independent DPP scans in one block of straight code fill each other's
+    __builtin_amdgcn_sched_barrier(0);   // all requests leave before anything waits for the first
+    // entry offsets of all rounds first: independent DPP scans in one block of straight code fill each other's
     // wait states (a scan alone is 7 dependent steps with 2 idle cycles between them)
-    uint32_t ent[kWTiles / 2];
+    uint32_t ent[R];
 #pragma unroll
-    for (uint32_t r = 0; r < kWTiles / 2; r++) {
+    for (uint32_t r = 0; r < R; r++) {
         const uint32_t cnt = (uint32_t)__builtin_popcount(code[r] & 0xffffu);
         ent[r] = (uint32_t)wave_inclusive_scan((int)cnt) - cnt;
     }
@@ -730,37 +746,37 @@ __device__ __forceinline__ void expand_pairs(const ExpandArgs &a, uint32_t mx, u
     // with one byte stage their entries
     uint32_t tail = 0;   // queued lanes (wave-uniform)
 #pragma unroll
-    for (uint32_t r = 0; r < kWTiles / 2; r++) {
+    for (uint32_t r = 0; r < R; r++) {
         const uint32_t c = code[r];
         const uint32_t m16 = c & 0xffffu;
         const bool multi = (m16 & (m16 - 1u)) != 0u;
         const uint64_t bm = __ballot(multi);
         if (bm) {   // wave-uniform
-            const uint32_t za = (uint32_t)__builtin_amdgcn_readlane((int)mz, 2 * r);
-            const uint32_t pm_a = (uint32_t)__builtin_amdgcn_readlane((int)my, 2 * r) >> 4, pm_b = (uint32_t)__builtin_amdgcn_readlane((int)my, 2 * r + 1) >> 4;
-            const bool second = lane >= (za >> 16);
+            const uint32_t za = (uint32_t)__builtin_amdgcn_readlane((int)mz, G * r);
             const uint32_t e = (za & 0xffffu) + ent[r];
-            const uint32_t val = (c >> 16) & 0xffu;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-            if (multi)   // {record index | tile << 28,  map | stage index << 16 | lane << 26}
-                list[tail + rank] = make_uint2((second ? pm_b + val + ((2u * r + 1u) << 28) : pm_a + val + ((2u * r) << 28)),
-                                               m16 | (e << 16) | ((c & 0x3f000000u) << 2));
+            // {the record's rank among its tile's records | tile of the item << 28,  map | stage index << 16 | lane << 26}
+            const uint32_t tile = G * r + ((c >> 30) & (G - 1u));
+            if (multi) list[tail + rank] = make_uint2(((c >> 16) & 0xffu) | (tile << 28), m16 | (e << 16) | ((c & 0x3f000000u) << 2));
             tail += (uint32_t)__builtin_popcountll(bm);
         }
     }
     lds_handoff();
-    // the first 64 queued lanes' records (an item rarely queues more)
+    // the first 64 queued lanes' records (an item rarely queues more): record index = first record of the lane's tile (lane
+    // `tile` of my holds its byte offset) + rank
+    const uint32_t my16 = my >> 4;
     const uint2 w0 = list[lane];
-    const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(recs, lane < tail ? (w0.x << 4) : kOOB, 0, 0);
+    const uint32_t base0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((w0.x >> 28) << 2), (int)my16);
+    const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(recs, lane < tail ? ((base0 + (w0.x & 0xffu)) << 4) : kOOB, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (uint32_t r = 0; r < kWTiles / 2; r++) {
+    for (uint32_t r = 0; r < R; r++) {
         const uint32_t c = code[r];
         const uint32_t m16 = c & 0xffffu;
-        const uint32_t za = (uint32_t)__builtin_amdgcn_readlane((int)mz, 2 * r);
-        const uint32_t e = (za & 0xffffu) + ent[r];   // index in the stage = in the item (tile 2r + 1 follows tile 2r)
+        const uint32_t za = (uint32_t)__builtin_amdgcn_readlane((int)mz, G * r);
+        const uint32_t e = (za & 0xffffu) + ent[r];   // index in the stage = in the item (the group's tiles follow each other)
         // first byte of the lane relative to the item: (tile << 10) + lane of the pack kernel * 16
-        const uint32_t src16 = ((c >> 20) & 0x3f0u) + (lane >= (za >> 16) ? (2u * r + 1u) << 10 : (2u * r) << 10);
+        const uint32_t src16 = ((c >> 20) & 0x3f0u) + ((G * r + ((c >> 30) & (G - 1u))) << 10);
         if (m16 != 0u && (m16 & (m16 - 1u)) == 0u)
             stage[e] = ((src16 + (uint32_t)__builtin_ctz(m16)) << 8) | ((c >> 16) & 0xffu);   // kernels.cu:314-315
     }
@@ -770,7 +786,8 @@ __device__ __forceinline__ void expand_pairs(const ExpandArgs &a, uint32_t mx, u
     for (uint32_t head = 64u; head < tail; head += 64u) {   // the rest, 64 at a time
         const bool on = head + lane < tail;
         const uint2 w = list[min(head + lane, kFList - 1u)];
-        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(recs, on ? (w.x << 4) : kOOB, 0, 0);
+        const uint32_t base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((w.x >> 28) << 2), (int)my16);
+        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(recs, on ? ((base + (w.x & 0xffu)) << 4) : kOOB, 0, 0);
         walk_records(on ? (w.y & 0xffffu) : 0u, (w.y >> 16) & 0x3ffu, ((w.x >> 28) << 10) | ((w.y >> 26) << 4),
                      make_uint4(q.x, q.y, q.z, q.w), stage, lane);
     }
@@ -916,7 +933,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         return;
     }
     if (kXAblate == 1) return;   // lab: prologue only
-    expand_pairs(a, m.x, m.y, ((bincl - both) & 0xffffu) | (nc << 16), s_list, s_stage, lane);
+    // quads when every four neighbouring tiles fill at most the 64 lanes of a round (all items of a webcam-like frame away
+    // from moving objects), pairs otherwise
+    const uint32_t nc_q = nc_b + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(nc + nc_b), 0x102 /* row_shl:2 */, 0xf, 0xf, true);
+    const bool quads = __ballot((lane & 3u) == 0u && nc + nc_q > 64u) == 0;   // wave-uniform
+    if (quads) expand_group<4>(a, m.x, m.y, ((bincl - both) & 0xffffu) | (nc << 16), s_list, s_stage, lane);
+    else expand_group<2>(a, m.x, m.y, ((bincl - both) & 0xffffu) | (nc << 16), s_list, s_stage, lane);
     lds_handoff();
     if (kXAblate < 2) flush_entries<WIRE>(a, s_stage, 0u, nent, xs0, dst0, w_xs, w_df, w_room);
 }

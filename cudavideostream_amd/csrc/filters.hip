@@ -35,26 +35,10 @@ __device__ __forceinline__ Px16 load_px16(const uint8_t *p, int nbytes) {
     return r;
 }
 
-// The same 48 bytes with non-temporal loads (MI355_FILT_NT_LOAD=1, a timing build): measured 10 % SLOWER (gray 2.07 -> 2.37 us
-// per frame, profiles/r04au): a 128-byte line is touched by three of these loads, 16 bytes per lane at a 48-byte
+// The colour frames of the filters are read with plain loads: non-temporal ones were measured 10 % SLOWER (gray 2.07 ->
+// 2.37 us per frame, profiles/r04au): a 128-byte line is touched by three of these loads, 16 bytes per lane at a 48-byte
 // stride, and a non-temporal line does not wait in the cache for the other two.
-#ifndef MI355_FILT_NT_LOAD
-#define MI355_FILT_NT_LOAD 0
-#endif
-__device__ __forceinline__ Px16 load_px16_once(const uint8_t *p) {
-#if MI355_FILT_NT_LOAD
-    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-    const v4 *q = reinterpret_cast<const v4 *>(p);
-    const v4 a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1), c = __builtin_nontemporal_load(q + 2);
-    Px16 r;
-    r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
-    r.w[4] = b.x; r.w[5] = b.y; r.w[6] = b.z; r.w[7] = b.w;
-    r.w[8] = c.x; r.w[9] = c.y; r.w[10] = c.z; r.w[11] = c.w;
-    return r;
-#else
-    return load_px16<true>(p, 48);
-#endif
-}
+__device__ __forceinline__ Px16 load_px16_once(const uint8_t *p) { return load_px16<true>(p, 48); }
 
 template <bool FAST>
 __device__ __forceinline__ void store_px16(uint8_t *p, const Px16 &r, int nbytes) {
@@ -76,16 +60,10 @@ __device__ __forceinline__ void store_px16(uint8_t *p, const Px16 &r, int nbytes
 // those per wave write every line three times over.  `wave_base` = address of the wave's first byte; every lane of
 // the wave must take part (caller checks with a ballot).  LDS: ds_write_b128 at a 48-byte stride is conflict-free
 // per 16 lanes (12 l mod 64 covers the 64 banks in 16 disjoint groups of 4).
-#ifndef MI355_FILT_LDS_STORE
-#define MI355_FILT_LDS_STORE 1
-#endif
 // ... and they are NON-TEMPORAL stores (round 4): a visualiser frame is written once and read by nobody on this path; kept
 // out of the caches it leaves them to the frames and logs of the diff that follows (fused gray+binarize 2.90 -> 2.74 us per
 // 1080p frame, config 3's chain 4.9 -> 4.75-4.85; the noise filter's output, which the diff reads next, gains nothing:
 // profiles/r04at_filters_nt_stores.log).
-#ifndef MI355_FILT_NT_STORE
-#define MI355_FILT_NT_STORE 1
-#endif
 __device__ __forceinline__ void store_px16_wave(uint8_t *wave_base, const Px16 &r, uint4 *lds /* 192 per wave */) {
     const uint32_t lane = threadIdx.x & 63u;
     lds[lane * 3u + 0u] = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
@@ -96,56 +74,25 @@ __device__ __forceinline__ void store_px16_wave(uint8_t *wave_base, const Px16 &
     uint4 *q = reinterpret_cast<uint4 *>(wave_base);
 #pragma unroll
     for (uint32_t j = 0; j < 3; j++) {
-#if MI355_FILT_NT_STORE
         typedef uint32_t v4 __attribute__((ext_vector_type(4)));
         const uint4 t = lds[j * 64u + lane];
         __builtin_nontemporal_store(v4{t.x, t.y, t.z, t.w}, reinterpret_cast<v4 *>(q + j * 64u + lane));
-#else
-        q[j * 64u + lane] = lds[j * 64u + lane];
-#endif
     }
 }
 
-// The load side of the same regrouping: three wave-contiguous 1 KiB loads, the lanes' 48-byte pieces read back from LDS.
-// Measured (profiles/r03t_filters_lds_ab.log): no gain for gray / binarize / red, the heat map slower (its LUT also
-// lives in LDS) -- the caches already serve the strided loads; kept as a build option, off.
-#ifndef MI355_FILT_LDS_LOAD
-#define MI355_FILT_LDS_LOAD 0
-#endif
-__device__ __forceinline__ Px16 load_px16_full(const uint8_t *in, size_t off) {
-#if MI355_FILT_LDS_LOAD
-    __shared__ uint4 s_l[4][192];
-    if (__ballot(true) == ~0ull) {   // the whole wave is here
-        const uint32_t lane = threadIdx.x & 63u;
-        uint4 *lds = s_l[threadIdx.x >> 6];
-        const uint4 *q = reinterpret_cast<const uint4 *>(in + off - (size_t)lane * 48u);
-        const uint4 a = q[lane], b = q[64u + lane], c = q[128u + lane];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the piece read back by the call before
-        __builtin_amdgcn_wave_barrier();
-        lds[lane] = a; lds[64u + lane] = b; lds[128u + lane] = c;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint4 x = lds[lane * 3u], y = lds[lane * 3u + 1u], z = lds[lane * 3u + 2u];
-        Px16 r;
-        r.w[0] = x.x; r.w[1] = x.y; r.w[2] = x.z; r.w[3] = x.w;
-        r.w[4] = y.x; r.w[5] = y.y; r.w[6] = y.z; r.w[7] = y.w;
-        r.w[8] = z.x; r.w[9] = z.y; r.w[10] = z.z; r.w[11] = z.w;
-        return r;
-    }
-#endif
-    return load_px16<true>(in + off, 48);
-}
+// (The same regrouping on the LOAD side -- three wave-contiguous 1 KiB loads, the lanes' 48-byte pieces read back from
+// LDS -- was measured and is not done: no gain for gray / binarize / red, the heat map slower (its LUT also lives in LDS):
+// the caches already serve the strided loads, profiles/r03t_filters_lds_ab.log.)
+__device__ __forceinline__ Px16 load_px16_full(const uint8_t *in, size_t off) { return load_px16<true>(in + off, 48); }
 
 // A lane's 48 bytes at out + off, through the wave-contiguous form when every lane of the wave stores a full piece.
 // `take` = this lane takes part (full 16 pixels, 16-byte aligned frame); lanes that do not fall back by themselves.
 __device__ __forceinline__ void store_px16_full(uint8_t *out, size_t off, const Px16 &q) {
-#if MI355_FILT_LDS_STORE
     __shared__ uint4 s_t[4][192];
     if (__ballot(true) == ~0ull) {   // the whole wave is here
         store_px16_wave(out + off - (size_t)(threadIdx.x & 63u) * 48u, q, s_t[threadIdx.x >> 6]);
         return;
     }
-#endif
     store_px16<true>(out + off, q, 48);
 }
 
@@ -756,11 +703,7 @@ __global__ __launch_bounds__(256) void k_red_stream_clear(uint8_t *out, size_t s
     if (slice >= nslices) return;   // wave-uniform
     const uint32_t first = offsets[blockIdx.y];
     const uint32_t *bd = bounds + (size_t)blockIdx.y * (nslices + 1u) + slice;
-#if defined(MI355_RED_ABLATE)
-    const uint32_t lo = bd[0], hi = lo + (bd[1] & 0u);    // timing builds only: the bare slice writes
-#else
     const uint32_t lo = bd[0], hi = bd[1];                // the entries of this slice
-#endif
     const uint32_t a = slice * kRedSlice, len = min(kRedSlice, nbytes - a);
     uint4 *sl = s_slice[wave];
     uint8_t *bytes = reinterpret_cast<uint8_t *>(sl);
@@ -782,13 +725,9 @@ __global__ __launch_bounds__(256) void k_red_stream_clear(uint8_t *out, size_t s
 #pragma unroll
     for (uint32_t j = 0; j < 3; j++) {
         const uint32_t o = (j * 64u + lane) * 16u;
-#if MI355_FILT_NT_STORE
         typedef uint32_t v4 __attribute__((ext_vector_type(4)));
         const uint4 t = sl[j * 64u + lane];
         if (o + 16u <= len) __builtin_nontemporal_store(v4{t.x, t.y, t.z, t.w}, reinterpret_cast<v4 *>(img + o));
-#else
-        if (o + 16u <= len) *reinterpret_cast<uint4 *>(img + o) = sl[j * 64u + lane];
-#endif
         else for (uint32_t k = o; k < len; k++) img[k] = bytes[k];
     }
 }
@@ -842,6 +781,38 @@ __device__ __forceinline__ uint32_t f32x4_to_u8x4(float a, float b, float c, flo
     return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(d), 3u, r);
 }
 
+// Sixteen results into four dwords with ONE instruction per byte: under the round-toward-zero mode v_cvt_pk_u8_f32
+// truncates by itself (and saturates to 0..255, negatives and NaN to 0) -- measured for the border cases on the MI355X
+// (tools/ubench/cvt_rtz.hip, profiles/r05_cvt_rtz.txt) and for every float in tests/test_filters_gpu.py's conversion
+// sweep.  The mode is switched inside ONE asm statement around the sixteen conversions only: the multiplies and adds of the
+// filter are data dependences of the statement or independent of it, none can be scheduled into it.
+__device__ __forceinline__ void f32x16_to_u8x16_rtz(const float (&f)[16], uint32_t (&o)[4]) {
+    asm volatile(
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"   // MODE[1:0], single-precision rounding: toward zero
+        "s_nop 1\n\t"
+        "v_cvt_pk_u8_f32 %0, %4, 0, 0\n\t"
+        "v_cvt_pk_u8_f32 %1, %8, 0, 0\n\t"
+        "v_cvt_pk_u8_f32 %2, %12, 0, 0\n\t"
+        "v_cvt_pk_u8_f32 %3, %16, 0, 0\n\t"
+        "v_cvt_pk_u8_f32 %0, %5, 1, %0\n\t"
+        "v_cvt_pk_u8_f32 %1, %9, 1, %1\n\t"
+        "v_cvt_pk_u8_f32 %2, %13, 1, %2\n\t"
+        "v_cvt_pk_u8_f32 %3, %17, 1, %3\n\t"
+        "v_cvt_pk_u8_f32 %0, %6, 2, %0\n\t"
+        "v_cvt_pk_u8_f32 %1, %10, 2, %1\n\t"
+        "v_cvt_pk_u8_f32 %2, %14, 2, %2\n\t"
+        "v_cvt_pk_u8_f32 %3, %18, 2, %3\n\t"
+        "v_cvt_pk_u8_f32 %0, %7, 3, %0\n\t"
+        "v_cvt_pk_u8_f32 %1, %11, 3, %1\n\t"
+        "v_cvt_pk_u8_f32 %2, %15, 3, %2\n\t"
+        "v_cvt_pk_u8_f32 %3, %19, 3, %3\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\t"   // back to round-to-nearest-even (the kernels' mode)
+        "s_nop 1"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+        : "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "v"(f[4]), "v"(f[5]), "v"(f[6]), "v"(f[7]), "v"(f[8]), "v"(f[9]), "v"(f[10]),
+          "v"(f[11]), "v"(f[12]), "v"(f[13]), "v"(f[14]), "v"(f[15]));
+}
+
 __device__ __forceinline__ float byte_f(uint32_t dw, int b) {  // b is a compile-time constant
     return (float)((dw >> (8 * b)) & 0xffu);                   // v_cvt_f32_ubyteN
 }
@@ -892,41 +863,47 @@ __device__ __forceinline__ float mul1(float a, float b) {
     return r;
 }
 
-#ifndef MI355_CONV_WAVES
-#define MI355_CONV_WAVES 4
-#endif
+// (106 registers: four waves per SIMD; two or three were measured 2-6 % slower, profiles/r05_conv.txt)
 template <bool SYM>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MI355_CONV_WAVES, MI355_CONV_WAVES)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_conv3x3_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, const float *k9, size_t stride) {
     constexpr int NP = 8;           // output pairs per lane and row (16 bytes)
     constexpr uint32_t kOut = 0x80000000u;   // beyond every frame (mi355_create: N < 2^31); + a row offset it does not wrap
     const uint32_t lane = threadIdx.x;
     const uint32_t frame_bytes = (uint32_t)rowbytes * (uint32_t)h;
-    const uint8_t *src = in + (size_t)blockIdx.z * stride;
-    const __amdgpu_buffer_rsrc_t dst = conv_rsrc(out + (size_t)blockIdx.z * stride, frame_bytes);
-    const uint32_t xb = (blockIdx.x * 64u + lane) * 16u;
-    const bool live = xb < (uint32_t)rowbytes;
-    const uint32_t col = live ? xb : kOut;   // a lane beyond the row end reads zeros and stores nothing
+    const __amdgpu_buffer_rsrc_t src = conv_rsrc(in + (size_t)blockIdx.z * stride, frame_bytes);
+    uint8_t *dst_base = out + (size_t)blockIdx.z * stride;
+    // The frame's (band of kStripRows rows, 16-byte strip) pairs are dealt to the lanes in one running number: a wave's
+    // lanes are neighbouring strips of a band and, where a band ends inside the wave, go on with the first strips of the
+    // next band (one wave per 64 strips of a band left 24 of the sixth wave's lanes idle at 1080p: 360 strips = 5.6 waves).
+    const uint32_t strips = (uint32_t)rowbytes / 16u, nbands = ((uint32_t)h + kStripRows - 1u) / kStripRows;
+    const uint32_t g = blockIdx.x * 64u + lane;
+    const uint32_t band = g / strips, strip = g - band * strips;
+    const bool live = band < nbands;
+    const uint32_t xb = strip * 16u;
+    const int y0 = (int)(band * kStripRows);   // (per lane)
+    // Byte offsets of row y0 - 1 (the walk's first row) in the frame: step k adds k rows.  Rows outside the image need no
+    // care: row -1 is a "negative" offset, i.e. one beyond the descriptor's records, and so is every row >= h -- the
+    // hardware returns zeros for them (kernels.cu:111-115) and drops their stores.  A lane without a strip, and the halo
+    // fetch of a lane that needs none, start beyond the records and stay there (kOut + 40 rows does not wrap).
+    const uint32_t col0 = live ? (uint32_t)((y0 - 1) * rowbytes) + xb : kOut;
+    const bool has_l = live && strip > 0u, has_r = live && strip + 1u < strips;
     // the dword beyond the wave's own kilobyte: lane 0 needs the one to its left, lane 63 the one to its right (zero
-    // outside the row, kernels.cu:111-115); the other lanes read nothing
-    const bool has_l = live && xb > 0u, has_r = live && xb + 16u < (uint32_t)rowbytes;
-    const uint32_t edge_col = lane == 0u ? (has_l ? xb - 4u : kOut) : (lane == 63u && has_r ? xb + 16u : kOut);
+    // outside the row); the other lanes read nothing
+    const uint32_t edge0 = lane == 0u ? (has_l ? col0 - 4u : kOut) : (lane == 63u && has_r ? col0 + 16u : kOut);
     const uint32_t mask_l = lane == 0u ? ~0u : 0u, mask_r = lane == 63u ? ~0u : 0u;
-    const int y0 = blockIdx.y * kStripRows;
-    const int y1 = min(y0 + kStripRows, h);
+    // where a band ends inside the wave the neighbour lane holds the other end of the image: no halo from there
+    const uint32_t keep_l = has_l ? ~0u : 0u, keep_r = has_r ? ~0u : 0u;
     float kk[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) kk[i] = k9[i];
 
     struct Row { uint32_t m[4]; uint32_t edge; };
-    auto load_row = [&](int r) {
-        // a row outside the image: a descriptor without records, every load returns zeros (no traffic)
-        const bool inside = r >= 0 && r < h;
-        const __amdgpu_buffer_rsrc_t d = conv_rsrc(src, inside ? frame_bytes : 0u);
-        const uint32_t rowoff = (uint32_t)min(max(r, 0), h - 1) * (uint32_t)rowbytes;
+    auto load_row = [&](int k) {   // row y0 - 1 + k of the lane's band
+        const uint32_t rowoff = (uint32_t)k * (uint32_t)rowbytes;
         Row v;
-        const cv_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(d, col + rowoff, 0, 0);
-        v.edge = __builtin_amdgcn_raw_buffer_load_b32(d, edge_col + rowoff, 0, 0);
+        const cv_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(src, col0 + rowoff, 0, 0);
+        v.edge = __builtin_amdgcn_raw_buffer_load_b32(src, edge0 + rowoff, 0, 0);
         v.m[0] = t.x; v.m[1] = t.y; v.m[2] = t.z; v.m[3] = t.w;
         return v;
     };
@@ -934,12 +911,14 @@ void k_conv3x3_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, const
     // of adjacent outputs.  With f[n] = byte xb - 3 + n (n = 0..21), output pair q = outputs (2q, 2q+1) takes its left
     // and right taps from e[q] = (f[2q], f[2q+1]) and e[q+3], and its middle tap from (f[2q+3], f[2q+4]) = (e[q+1].y,
     // e[q+2].x): an odd-aligned pair.
-    auto step = [&](int r, const Row &v, f32x2 (&B)[NP], f32x2 (&M)[NP], f32x2 (&T)[NP]) {
+    // (`v` is refilled with row r + 3 as soon as its bytes have been converted: three rows in flight, and no register
+    // copies to rotate the ring -- a copy of a row that is still on its way would wait for it)
+    auto step = [&](int k, Row &v, f32x2 (&B)[NP], f32x2 (&M)[NP], f32x2 (&T)[NP]) {   // k: row y0 - 1 + k
         // the neighbour lanes' dwords next to the seam (lanes without a neighbour get 0), lanes 0 / 63: the fetched one
         uint32_t l = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.m[3], 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
         uint32_t rr = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.m[0], 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
-        l = (v.edge & mask_l) | l;
-        rr = (v.edge & mask_r) | rr;
+        l = ((v.edge & mask_l) | l) & keep_l;
+        rr = ((v.edge & mask_r) | rr) & keep_r;
         f32x2 e[NP + 3];
         e[0] = f32x2{byte_f(l, 1), byte_f(l, 2)};
         e[1] = f32x2{byte_f(l, 3), byte_f(v.m[0], 0)};
@@ -949,6 +928,9 @@ void k_conv3x3_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, const
             e[3 + 2 * d] = f32x2{byte_f(v.m[d], 3), d + 1 < 4 ? byte_f(v.m[d + 1 < 4 ? d + 1 : d], 0) : byte_f(rr, 0)};
         }
         e[NP + 2] = f32x2{byte_f(rr, 1), byte_f(rr, 2)};
+        __builtin_amdgcn_sched_barrier(0);
+        v = load_row(k + 3);
+        __builtin_amdgcn_sched_barrier(0);
         if (SYM) {
             f32x2 pc[NP + 3], pe[NP + 3];   // corner * e, edge * e
             float kc;                       // the centre weight in a vector register (add1 / mul1 take vector operands)
@@ -981,13 +963,19 @@ void k_conv3x3_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, const
                 T[q] = (kk[0] * e[q] + kk[1] * c) + kk[2] * e[q + 3];
             }
         }
-        if (r - 1 >= y0) {   // output row r-1 is complete (r <= y1 here)
-            cv_u32x4 o;
-            o.x = f32x4_to_u8x4(B[0].x, B[0].y, B[1].x, B[1].y);   // :131-133
-            o.y = f32x4_to_u8x4(B[2].x, B[2].y, B[3].x, B[3].y);
-            o.z = f32x4_to_u8x4(B[4].x, B[4].y, B[5].x, B[5].y);
-            o.w = f32x4_to_u8x4(B[6].x, B[6].y, B[7].x, B[7].y);
-            __builtin_amdgcn_raw_buffer_store_b128(o, dst, col + (uint32_t)(r - 1) * (uint32_t)rowbytes, 0, 0);
+        {   // output row r-1 is complete; rows outside the strip (the walk's first step, the steps that round it up to
+            // whole groups of three) go to a descriptor without records and are dropped -- no branch: behind a branch the
+            // compiler loses count of the loads in flight and waits for all of them at the head of the loop
+            const float bf[16] = {B[0].x, B[0].y, B[1].x, B[1].y, B[2].x, B[2].y, B[3].x, B[3].y,
+                                  B[4].x, B[4].y, B[5].x, B[5].y, B[6].x, B[6].y, B[7].x, B[7].y};
+            uint32_t ow[4];
+            f32x16_to_u8x16_rtz(bf, ow);                           // :131-133
+            const cv_u32x4 o = {ow[0], ow[1], ow[2], ow[3]};
+            // output row y0 - 2 + k: the band's rows are k = 2 .. kStripRows + 1 (a descriptor without records drops the
+            // others); rows >= h of the image's last band are beyond the records by themselves
+            const bool mine = k >= 2 && k <= kStripRows + 1;
+            const __amdgpu_buffer_rsrc_t d = conv_rsrc(dst_base, mine ? frame_bytes : 0u);
+            __builtin_amdgcn_raw_buffer_store_b128(o, d, col0 + (uint32_t)(k - 1) * (uint32_t)rowbytes, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);   // one row at a time: fewer products live at once
     };
@@ -997,17 +985,20 @@ void k_conv3x3_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, const
     for (int q = 0; q < NP; q++) a0[q] = a1[q] = a2[q] = f32x2{0.0f, 0.0f};
     // rows y0-1 .. y1 are walked; three rows are in flight ahead of the one being computed (requests for rows beyond y1
     // read rows of the strip below or, beyond the image, nothing)
-    Row q0 = load_row(y0 - 1), q1 = load_row(y0), q2 = load_row(y0 + 1);
-    for (int r = y0 - 1; r <= y1; r += 3) {      // the three accumulator sets rotate through the roles
-        const Row n0 = load_row(r + 3);
-        step(r, q0, a0, a1, a2);
-        if (r + 1 > y1) break;
-        const Row n1 = load_row(r + 4);
-        step(r + 1, q1, a1, a2, a0);
-        if (r + 2 > y1) break;
-        const Row n2 = load_row(r + 5);
-        step(r + 2, q2, a2, a0, a1);
-        q0 = n0; q1 = n1; q2 = n2;
+    // (requested in the order they are used: the wait at the head of the loop is the worse of what the code in front of
+    // the loop and the loop's own end leave in flight, and the compiler's scheduler, left alone, asked for row y0 - 1 last)
+    Row q0 = load_row(0);
+    __builtin_amdgcn_sched_barrier(0);
+    Row q1 = load_row(1);
+    __builtin_amdgcn_sched_barrier(0);
+    Row q2 = load_row(2);
+    __builtin_amdgcn_sched_barrier(0);
+    // rows y0 - 1 .. y0 + kStripRows in whole groups of three (the accumulator sets and the row buffers rotate through
+    // their roles); the step too many computes a row nobody stores
+    for (int k = 0; k <= kStripRows + 1; k += 3) {
+        step(k, q0, a0, a1, a2);
+        step(k + 1, q1, a1, a2, a0);
+        step(k + 2, q2, a2, a0, a1);
     }
 }
 
@@ -1108,8 +1099,10 @@ hipError_t launch_conv3x3(const uint8_t *in, uint8_t *out, int w, int h, const f
                           FrameBatch fb, hipStream_t s) {
     if (w <= 0 || h <= 0 || fb.nframes <= 0) return hipSuccess;
     const int rowbytes = 3 * w;
-    if (rowbytes % 16 == 0 && aligned16(in) && aligned16(out) && fb.stride % 16 == 0) {
-        const dim3 grid((rowbytes / 16 + 63) / 64, (h + kStripRows - 1) / kStripRows, (unsigned)fb.nframes);
+    // (the strip kernel keeps lanes without work at an offset of 2^31 plus up to 40 rows: rows below 2^31 / 40 bytes)
+    if (rowbytes % 16 == 0 && aligned16(in) && aligned16(out) && fb.stride % 16 == 0 && rowbytes < (1 << 25)) {
+        const unsigned lanes = (unsigned)(rowbytes / 16) * (unsigned)((h + kStripRows - 1) / kStripRows);   // (band, strip) pairs
+        const dim3 grid((lanes + 63u) / 64u, 1, (unsigned)fb.nframes);
         if (k9_symmetric)
             hipLaunchKernelGGL((k_conv3x3_strip<true>), grid, dim3(64), 0, s, in, out, rowbytes, h, k9, fb.stride);
         else

@@ -239,6 +239,32 @@ def test_conv3x3_sharpen_and_edge_kernels_saturate_the_same_way(po, w, h):
             assert np.array_equal(d_o.cpu().numpy(), want)
 
 
+def test_conv3x3_conversion_sweep(po):
+    """float -> byte of the strip kernel (v_cvt_pk_u8_f32 under round-toward-zero, one instruction per byte) against the
+    oracle's truncate-and-saturate for products all over the number line: a centre-only kernel g makes every output
+    trunc_sat(fl(g * x)) for x = 0..255 -- gains that land on .5, just below an integer, at 254.99 / 255.0, negative, huge,
+    infinite and NaN ones, and a few hundred random ones; then the same gains as ONE tap of an asymmetric kernel (the
+    general form of the kernel) with the other taps zero."""
+    w, h = 128, 8
+    img = np.tile(np.arange(256, dtype=np.uint8), 3 * w * h // 256)
+    rng = np.random.default_rng(77)
+    gains = [0.5, 1.5, 0.25, 0.75, 1.0, 0.99999994, 1.0000001, 0.3333333, 0.6666667, 2.0, 127.99999 / 255, 254.99 / 255,
+             254.999 / 255, 255.5 / 255, 1e-30, -1e-30, -0.5, -1.0, 3.0e38, -3.0e38, float("inf"), float("-inf"), float("nan"),
+             1.0 / 3, 1.0 / 7, 255.0 / 256, 1.0039216]
+    gains += list(rng.uniform(-2.0, 3.0, 200)) + list(np.exp(rng.uniform(-8, 8, 100)))
+    with np.errstate(all="ignore"):
+        for g in gains:
+            for sym in (True, False):
+                k = np.zeros(9, np.float32)
+                k[4 if sym else 5] = np.float32(g)       # (0, 0, 0, 0, g, ...) is "symmetric" bit for bit; one off-centre tap is not
+                want = po.conv3x3(img, w, h, k)
+                with CUDACore(w, h, k=k) as core:
+                    d_o = dev_out(img.size)
+                    core.conv3x3(to_dev(img), d_o); core.synchronize()
+                    got = d_o.cpu().numpy()
+                assert np.array_equal(got, want), (g, sym, np.flatnonzero(got != want)[:5])
+
+
 def test_conv_requires_kernel_and_out_of_place():
     with CUDACore(8, 8) as core:
         d = dev_out(192)
