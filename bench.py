@@ -396,7 +396,10 @@ def rehearsal_env():
     if not os.path.exists(mock):
         raise SystemExit(f"bench.py --rehearse-on-one-gpu: {mock} is missing (python -c 'import __graft_entry__ as g; g.build()')")
     return {"MI355_RCCL_LIB": os.environ.get("MI355_RCCL_LIB", mock),
-            "MOCK_RCCL_SHM": os.environ.get("MOCK_RCCL_SHM", f"/mi355bench_{os.getpid()}")}
+            "MOCK_RCCL_SHM": os.environ.get("MOCK_RCCL_SHM", f"/mi355bench_{os.getpid()}"),
+            # payloads are staged through shared host memory: room for a few ranks' batches at a time, and patience
+            "MOCK_RCCL_SHM_MB": os.environ.get("MOCK_RCCL_SHM_MB", "256"),
+            "MOCK_RCCL_TIMEOUT_S": os.environ.get("MOCK_RCCL_TIMEOUT_S", "60")}
 
 
 def main():

@@ -545,7 +545,7 @@ hipError_t launch_scan(const uint4 *meta, uint32_t *roff, uint64_t *totals, uint
 // start at arbitrary byte addresses (gfx950 global stores need no alignment).
 __device__ __forceinline__ void store_u32_unaligned(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 
-// Hand-off between lanes of ONE wave through LDS (k_expand is a single-wave workgroup): the DS operations of a
+// Hand-off between lanes of ONE wave through LDS (the waves of k_expand share nothing): the DS operations of a
 // wave execute in order, so this costs nothing in hardware; it keeps the compiler from moving LDS accesses
 // across the hand-off.
 __device__ __forceinline__ void lds_handoff() {
@@ -579,7 +579,7 @@ __device__ __forceinline__ void store_out1(uint8_t *p, uint32_t v) {   // any by
 template <bool WIRE>
 __device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint32_t *stage, uint32_t first, uint32_t count,
                                               uint32_t xs0, uint32_t dst0, uint8_t *w_xs, uint8_t *w_df, size_t w_room) {
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
     uint8_t *xsp, *dfp;
     uint32_t n;
     if (WIRE) {
@@ -868,18 +868,25 @@ __device__ __forceinline__ void expand_tiles(const ExpandArgs &a, const uint4 *t
 }
 
 template <bool WIRE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_expand(const ExpandArgs a) {
-    __shared__ __attribute__((aligned(16))) uint2 s_list[kFList];         // pair path: the item's queued (multi-byte) lanes; tile path: the 16 tiles' facts
-    __shared__ __attribute__((aligned(16))) uint32_t s_stage[kWStage];    // (byte index relative to the item's first tile) << 8 | difference
-    // 5120 bytes of LDS: 32 single-wave workgroups per CU
+__global__ __launch_bounds__(64 * kXWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_expand(const ExpandArgs a) {
+    // kXWaves (= 1) independent waves per workgroup, an item each (nothing is shared, no barrier).  The bare dispatch of the
+    // 97 280 single-wave workgroups of a 1080p batch takes 21 us, that of 24 320 four-wave workgroups 8 -- and the whole kernel
+    // is 5 % SLOWER with them (117-120 -> 124-127 us alone, 130 with eight waves; pipelined batch unchanged or worse): the
+    // dispatch runs beside the execution, it is not what the kernel waits for (profiles/r05i_expand_waves_per_workgroup.log)
+    __shared__ __attribute__((aligned(16))) uint2 s_lists[kXWaves][kFList];         // group path: the item's queued (multi-byte) lanes; tile path: the 16 tiles' facts
+    __shared__ __attribute__((aligned(16))) uint32_t s_stages[kXWaves][kWStage];    // (byte index relative to the item's first tile) << 8 | difference
+    // 5120 bytes of LDS per wave: 32 waves per CU
     // beside the next batch's pack kernel (pipelined batches) these short, latency-bound waves must not queue for
     // issue slots behind the older, issue-hungry pack waves
     __builtin_amdgcn_s_setprio(2);
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint2 *const s_list = s_lists[wave];
+    uint32_t *const s_stage = s_stages[wave];
     if (kXAblate == 9) return;   // lab: nothing but the dispatch of the grid
     asm volatile("v_mov_b32 v63, 0" ::: "v63");   // 64 declared vector registers (above)
-    const uint32_t t = blockIdx.y, sub = blockIdx.x;
-    if (sub * kWTiles >= a.ntiles) return;   // grid.x is padded to a multiple of 8 (see launch_expand)
+    const uint32_t t = blockIdx.y, sub = blockIdx.x * kXWaves + wave;
+    if (sub * kWTiles >= a.ntiles) return;   // the grid is padded (see launch_expand)
     const uint32_t ngroups = (a.ntiles + kXTiles - 1) / kXTiles;
     // lane L < 16: meta word of tile 16 sub + L = {code offset, record offset, flagged bytes, candidates | multi-byte
     // lanes << 16}; the other lanes (and tiles beyond the frame) read nothing and get zeros
@@ -950,12 +957,12 @@ hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s) {
     // tile's code log holds the codes of two consecutive frames, a line of its record log those of two or three, and the
     // L2s of the XCDs do not share -- without the padding the expander's requests to memory rise by 78 % (TCC_EA0_RDREQ
     // 1.87 M -> 3.33 M per batch, L2 hit rate 55 % -> 38 %, profiles/r04_tcc_grid_padding.txt).
-    const uint32_t gx = (a.ntiles + kWTiles - 1) / kWTiles;
+    const uint32_t gx = ((a.ntiles + kWTiles - 1) / kWTiles + kXWaves - 1) / kXWaves;   // workgroups per frame
     const dim3 grid((gx + 7u) / 8u * 8u, nframes);
     if (a.wire)
-        hipLaunchKernelGGL(k_expand<true>, grid, dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_expand<true>, grid, dim3(64 * kXWaves), 0, s, a);
     else
-        hipLaunchKernelGGL(k_expand<false>, grid, dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_expand<false>, grid, dim3(64 * kXWaves), 0, s, a);
     return hipGetLastError();
 }
 

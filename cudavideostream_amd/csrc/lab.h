@@ -5,6 +5,7 @@
 //   -DMI355_LAB=1 -DMI355_ABLATE=n   pack kernel: 1 = no log stores, 2 = also no meta stores, 3 = loads + a fold of the state only
 //                 -DMI355_XABLATE=n  expander: 1 = prologue only, 2 = + code loads, 3 = + rounds, 9 = nothing but the dispatch
 //                 -DMI355_PAD=n      n extra vector instructions per frame and tile of the pack kernel
+//                 -DMI355_XWAVES=n   waves (= items) per workgroup of the expander
 // to price parts of the kernels (outputs of such builds are wrong by design; only their times matter).  Nothing else in
 // the library is switchable at build time, and nothing but the variables documented in include/mi355diff.h at run time.
 #ifndef MI355_LAB_H_
@@ -20,9 +21,12 @@ namespace mi355 {
 #ifndef MI355_PAD
 #define MI355_PAD 0
 #endif
-constexpr int kAblate = MI355_ABLATE, kXAblate = MI355_XABLATE, kPad = MI355_PAD;
+#ifndef MI355_XWAVES
+#define MI355_XWAVES 1
+#endif
+constexpr int kAblate = MI355_ABLATE, kXAblate = MI355_XABLATE, kPad = MI355_PAD, kXWaves = MI355_XWAVES;
 #else
-constexpr int kAblate = 0, kXAblate = 0, kPad = 0;
+constexpr int kAblate = 0, kXAblate = 0, kPad = 0, kXWaves = 1;
 #endif
 }  // namespace mi355
 #endif

@@ -99,9 +99,11 @@ int mi355_synchronize(mi355_core *core);
  * (cudavideostream_amd/core.py holds such references itself until synchronize().) */
 
 /* Options.  The schedule of the batches on the core's own stream can be tuned per core; RESULTS never depend on it.
- * Changing an option first waits for the work the core has queued.  The library reads exactly ONE environment
- * variable: MI355_PIPELINE=0 makes MI355_OPT_PIPELINE default to 0 for every core of the process (a switch for the
- * operator of an unmodified server binary); nothing else in the environment steers it. */
+ * Changing an option first waits for the work the core has queued.  Of the environment the library reads two variables
+ * and nothing else: MI355_PIPELINE=0 makes MI355_OPT_PIPELINE default to 0 for every core of the process (a switch for
+ * the operator of an unmodified server binary); and, in the multi-GPU entry points only, MI355_RCCL_LIB=path names
+ * another library with the ten RCCL entry points they bind instead of librccl.so.1 (the tests' stand-ins, which let
+ * several ranks share the one GPU of a test box). */
 #define MI355_OPT_PIPELINE 1     /* 1 (default): own-stream batches are pipelined (below); 0: one kernel after the other */
 #define MI355_OPT_SPLIT_PCT 2    /* 50 (default): a pipelined batch is packed by two launches, this share of the tiles on
                                   * the first; 5..95, or 0 = one launch */

@@ -46,7 +46,7 @@ constexpr int kMaxWorlds = 16, kMaxRanks = 16, kMaxMsgs = 1024;
 constexpr uint32_t kMagic = 0x600DF00Du;
 
 struct Msg {
-    uint32_t state;   // 0 free, 1 posted (payload staged), 2 withdrawn by its sender
+    uint32_t state;   // 0 free, 1 posted (payload staged), 3 reserved (its sender is staging the payload)
     uint32_t world, src, dst, channel;   // channel 0: all-gather pieces, 1: point to point
     uint64_t seq, bytes, arena_off;
 };
@@ -60,8 +60,7 @@ struct Shm {
     Msg msgs[kMaxMsgs];
     uint64_t seq_post[kMaxWorlds][kMaxRanks][kMaxRanks][2];   // next sequence number a sender gives out
     uint64_t seq_take[kMaxWorlds][kMaxRanks][kMaxRanks][2];   // next sequence number the receiver takes
-    uint64_t arena_bytes, arena_used;
-    uint32_t live;   // staged payloads not yet consumed: the arena is a bump allocator that empties when this reaches 0
+    uint64_t arena_bytes;   // payloads live in [arena_off, arena_off + bytes) of their message slot: first fit over the live slots
 };
 
 Shm *g_shm = nullptr;
@@ -150,61 +149,71 @@ thread_local int t_depth = 0;
 
 size_t elem(ncclDataType_t t) { return t == ncclInt8 || t == ncclUint8 ? 1 : t == ncclInt32 || t == ncclUint32 ? 4 : 8; }
 
+// With the lock held: a free message slot and a gap of `need` bytes in the arena (first fit between the live payloads).
+bool reserve(size_t need, int &slot, uint64_t &off) {
+    slot = -1;
+    struct Span { uint64_t off, len; } live[kMaxMsgs];
+    int n = 0;
+    for (int i = 0; i < kMaxMsgs; i++) {
+        const Msg &m = g_shm->msgs[i];
+        if (!m.state) { if (slot < 0) slot = i; continue; }
+        live[n++] = Span{m.arena_off, (m.bytes + 255) & ~(uint64_t)255};
+    }
+    if (slot < 0) return false;
+    for (int i = 1; i < n; i++)   // insertion sort by offset (a few dozen at most)
+        for (int j = i; j > 0 && live[j].off < live[j - 1].off; j--) { const Span t = live[j]; live[j] = live[j - 1]; live[j - 1] = t; }
+    uint64_t at = 0;
+    for (int i = 0; i < n; i++) {
+        if (live[i].off >= at + need) break;
+        at = live[i].off + live[i].len > at ? live[i].off + live[i].len : at;
+    }
+    if (at + need > g_shm->arena_bytes) return false;
+    off = at;
+    return true;
+}
+
 // Stages `bytes` of device memory for (world, me -> dst, channel); returns the message slot or -1.
 int post(MockComm *c, int dst, int channel, const void *src, size_t bytes, hipStream_t stream) {
     if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return -1;
     uint64_t off = 0;
+    int slot = -1;
     {
         Lock lk;
-        const size_t need = (bytes + 255) & ~(size_t)255;
+        const size_t need = ((bytes ? bytes : 1) + 255) & ~(size_t)255;
         if (need > g_shm->arena_bytes) { fprintf(stderr, "mock rccl (ipc): a message of %zu bytes exceeds the arena (MOCK_RCCL_SHM_MB)\n", bytes); return -1; }
-        if (!lk.wait([&] { return g_shm->arena_used + need <= g_shm->arena_bytes; })) {
-            fprintf(stderr, "mock rccl (ipc): rank %d: no room in the arena (timed out)\n", c->rank);
+        if (!lk.wait([&] { return reserve(need, slot, off); })) {
+            fprintf(stderr, "mock rccl (ipc): rank %d: no room in the arena or the message table (timed out)\n", c->rank);
             return -1;
         }
-        off = g_shm->arena_used;
-        g_shm->arena_used += need;
-        g_shm->live++;
+        g_shm->msgs[slot] = Msg{3u, (uint32_t)c->world, (uint32_t)c->rank, (uint32_t)dst, (uint32_t)channel, 0, bytes, off};
     }
-    if (bytes && hipMemcpy(g_arena + off, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    const bool ok = !bytes || hipMemcpy(g_arena + off, src, bytes, hipMemcpyDeviceToHost) == hipSuccess;
     Lock lk;
-    for (int i = 0; i < kMaxMsgs; i++) {
-        Msg &m = g_shm->msgs[i];
-        if (m.state) continue;
-        m = Msg{1u, (uint32_t)c->world, (uint32_t)c->rank, (uint32_t)dst, (uint32_t)channel,
-                g_shm->seq_post[c->world][c->rank][dst][channel]++, bytes, off};
-        pthread_cond_broadcast(&g_shm->cv);
-        return i;
-    }
-    fprintf(stderr, "mock rccl (ipc): message table full\n");
-    return -1;
+    Msg &m = g_shm->msgs[slot];
+    if (!ok) { m.state = 0; pthread_cond_broadcast(&g_shm->cv); return -1; }
+    m.seq = g_shm->seq_post[c->world][c->rank][dst][channel]++;
+    m.state = 1;
+    pthread_cond_broadcast(&g_shm->cv);
+    return slot;
 }
 
 void release(Msg &m) {   // with the lock held: the payload leaves the arena
     m.state = 0;
-    if (--g_shm->live == 0) g_shm->arena_used = 0;
     pthread_cond_broadcast(&g_shm->cv);
 }
 
-// Takes the next message of (world, src -> me, channel) into device memory on `stream`.
-bool take(MockComm *c, int src, int channel, void *dst, size_t bytes, hipStream_t stream) {
-    int slot = -1;
-    {
-        Lock lk;
-        const uint64_t want = g_shm->seq_take[c->world][src][c->rank][channel];
-        auto find = [&] {
-            for (int i = 0; i < kMaxMsgs; i++) {
-                const Msg &m = g_shm->msgs[i];
-                if (m.state == 1 && (int)m.world == c->world && (int)m.src == src && (int)m.dst == c->rank && (int)m.channel == channel && m.seq == want) { slot = i; return true; }
-            }
-            return false;
-        };
-        if (!lk.wait(find)) {
-            fprintf(stderr, "mock rccl (ipc): rank %d: %s from rank %d never met its partner (timed out)\n", c->rank,
-                    channel ? "receive" : "all-gather piece", src);
-            return false;
-        }
+// With the lock held: the slot of the next message of (world, src -> me, channel), or -1.
+int find_msg(MockComm *c, int src, int channel) {
+    const uint64_t want = g_shm->seq_take[c->world][src][c->rank][channel];
+    for (int i = 0; i < kMaxMsgs; i++) {
+        const Msg &m = g_shm->msgs[i];
+        if (m.state == 1 && (int)m.world == c->world && (int)m.src == src && (int)m.dst == c->rank && (int)m.channel == channel && m.seq == want) return i;
     }
+    return -1;
+}
+
+// Moves message `slot` into device memory on `stream` and frees it.
+bool consume(MockComm *c, int slot, int src, int channel, void *dst, size_t bytes, hipStream_t stream) {
     Msg &m = g_shm->msgs[slot];
     bool ok = m.bytes == bytes;
     if (!ok) fprintf(stderr, "mock rccl (ipc): send of %llu bytes meets receive of %zu\n", (unsigned long long)m.bytes, bytes);
@@ -215,6 +224,34 @@ bool take(MockComm *c, int src, int channel, void *dst, size_t bytes, hipStream_
     g_shm->seq_take[c->world][src][c->rank][channel]++;
     release(m);
     return ok;
+}
+
+// What a rank still has to receive; taken in whatever order the messages arrive (the senders share one arena: waiting
+// for rank 1's payload while the arena is full of rank 2's and 3's would never end).
+struct Want { MockComm *c; int src, channel; void *dst; size_t bytes; hipStream_t stream; bool done; };
+
+bool take_all(std::vector<Want> &wants) {
+    for (size_t left = wants.size(); left; left--) {
+        int slot = -1;
+        Want *w = nullptr;
+        {
+            Lock lk;
+            auto any = [&] {
+                for (Want &x : wants)
+                    if (!x.done && (slot = find_msg(x.c, x.src, x.channel)) >= 0) { w = &x; return true; }
+                return false;
+            };
+            if (!lk.wait(any)) {
+                for (Want &x : wants)
+                    if (!x.done) fprintf(stderr, "mock rccl (ipc): rank %d: %s from rank %d never met its partner (timed out)\n", x.c->rank,
+                                         x.channel ? "receive" : "all-gather piece", x.src);
+                return false;
+            }
+        }
+        w->done = true;
+        if (!consume(w->c, slot, w->src, w->channel, w->dst, w->bytes, w->stream)) return false;
+    }
+    return true;
 }
 
 ncclResult_t flush() {
@@ -234,17 +271,21 @@ ncclResult_t flush() {
                 if (s >= 0) posted.push_back(s);
             }
     }
-    // 2. everything it receives
+    // 2. everything it receives.  Several receives from ONE sender on one channel complete in the order of issue (each
+    //    waits for that sender's next sequence number); across senders, in the order of arrival.
+    std::vector<Want> wants;
     for (Op &o : ops) {
-        if (!ok) break;
-        if (o.kind == 2) ok &= take(o.comm, o.peer, 1, o.dst, o.bytes, o.stream);
+        if (o.kind == 2) wants.push_back(Want{o.comm, o.peer, 1, o.dst, o.bytes, o.stream, false});
         if (o.kind == 0) {
             ok = ok && hipSetDevice(o.comm->device) == hipSuccess &&
                  hipMemcpyAsync((char *)o.dst + (size_t)o.comm->rank * o.bytes, o.src, o.bytes, hipMemcpyDeviceToDevice, o.stream) == hipSuccess;
-            for (int r = 0; r < o.comm->nranks && ok; r++)
-                if (r != o.comm->rank) ok &= take(o.comm, r, 0, (char *)o.dst + (size_t)r * o.bytes, o.bytes, o.stream);
+            for (int r = 0; r < o.comm->nranks; r++)
+                if (r != o.comm->rank) wants.push_back(Want{o.comm, r, 0, (char *)o.dst + (size_t)r * o.bytes, o.bytes, o.stream, false});
         }
     }
+    // (receives of one (sender, channel) must be consumed in the order they were posted: find_msg hands out the next
+    // sequence number, and take_all gives it to the FIRST unfinished want of that sender -- which is the oldest)
+    if (ok) ok = take_all(wants);
     // 3. its sends must have been taken (RCCL's group end returns when the rank's operations are complete); what nobody
     //    took is withdrawn
     {
