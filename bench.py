@@ -377,6 +377,8 @@ def spawn_ranks(args):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     shm = None
     if args.rehearse_on_one_gpu:
+        if args.gpus > 5:   # the GPU boxes of this project allow six processes on a card: five ranks + rank 0's rocm-smi
+            raise SystemExit("bench.py --rehearse-on-one-gpu: at most 5 ranks on the one GPU")
         env.update(rehearsal_env())
         shm = env["MOCK_RCCL_SHM"]
     try:

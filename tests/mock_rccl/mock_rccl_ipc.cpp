@@ -49,6 +49,7 @@ struct Msg {
     uint32_t state;   // 0 free, 1 posted (payload staged), 3 reserved (its sender is staging the payload)
     uint32_t world, src, dst, channel;   // channel 0: all-gather pieces, 1: point to point
     uint64_t seq, bytes, arena_off;
+    uint64_t uid;   // never reused: a sender that waits for ITS message to be taken must not mistake the slot's next tenant for it
 };
 
 struct Shm {
@@ -56,6 +57,7 @@ struct Shm {
     pthread_mutex_t mu;
     pthread_cond_t cv;
     uint32_t id_counter;
+    uint64_t uid_counter;
     struct World { char key[128]; uint32_t used, nranks, joined; } worlds[kMaxWorlds];
     Msg msgs[kMaxMsgs];
     uint64_t seq_post[kMaxWorlds][kMaxRanks][kMaxRanks][2];   // next sequence number a sender gives out
@@ -173,7 +175,7 @@ bool reserve(size_t need, int &slot, uint64_t &off) {
 }
 
 // Stages `bytes` of device memory for (world, me -> dst, channel); returns the message slot or -1.
-int post(MockComm *c, int dst, int channel, const void *src, size_t bytes, hipStream_t stream) {
+int post(MockComm *c, int dst, int channel, const void *src, size_t bytes, hipStream_t stream, uint64_t *uid = nullptr) {
     if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return -1;
     uint64_t off = 0;
     int slot = -1;
@@ -185,7 +187,7 @@ int post(MockComm *c, int dst, int channel, const void *src, size_t bytes, hipSt
             fprintf(stderr, "mock rccl (ipc): rank %d: no room in the arena or the message table (timed out)\n", c->rank);
             return -1;
         }
-        g_shm->msgs[slot] = Msg{3u, (uint32_t)c->world, (uint32_t)c->rank, (uint32_t)dst, (uint32_t)channel, 0, bytes, off};
+        g_shm->msgs[slot] = Msg{3u, (uint32_t)c->world, (uint32_t)c->rank, (uint32_t)dst, (uint32_t)channel, 0, bytes, off, ++g_shm->uid_counter};
     }
     const bool ok = !bytes || hipMemcpy(g_arena + off, src, bytes, hipMemcpyDeviceToHost) == hipSuccess;
     Lock lk;
@@ -193,6 +195,7 @@ int post(MockComm *c, int dst, int channel, const void *src, size_t bytes, hipSt
     if (!ok) { m.state = 0; pthread_cond_broadcast(&g_shm->cv); return -1; }
     m.seq = g_shm->seq_post[c->world][c->rank][dst][channel]++;
     m.state = 1;
+    if (uid) *uid = m.uid;
     pthread_cond_broadcast(&g_shm->cv);
     return slot;
 }
@@ -259,16 +262,18 @@ ncclResult_t flush() {
     ops.swap(t_ops);
     if (ops.empty()) return ncclSuccess;
     bool ok = true;
-    std::vector<int> posted;
+    struct Sent { int slot; uint64_t uid; };
+    std::vector<Sent> posted;
     // 1. everything this rank sends (an all-gather: its piece to every other rank)
     for (Op &o : ops) {
-        if (o.kind == 1) { const int s = post(o.comm, o.peer, 1, o.src, o.bytes, o.stream); ok &= s >= 0; if (s >= 0) posted.push_back(s); }
+        uint64_t uid = 0;
+        if (o.kind == 1) { const int s = post(o.comm, o.peer, 1, o.src, o.bytes, o.stream, &uid); ok &= s >= 0; if (s >= 0) posted.push_back(Sent{s, uid}); }
         if (o.kind == 0)
             for (int r = 0; r < o.comm->nranks && ok; r++) {
                 if (r == o.comm->rank) continue;
-                const int s = post(o.comm, r, 0, o.src, o.bytes, o.stream);
+                const int s = post(o.comm, r, 0, o.src, o.bytes, o.stream, &uid);
                 ok &= s >= 0;
-                if (s >= 0) posted.push_back(s);
+                if (s >= 0) posted.push_back(Sent{s, uid});
             }
     }
     // 2. everything it receives.  Several receives from ONE sender on one channel complete in the order of issue (each
@@ -290,11 +295,12 @@ ncclResult_t flush() {
     //    took is withdrawn
     {
         Lock lk;
-        auto all_taken = [&] { for (int s : posted) if (g_shm->msgs[s].state == 1) return false; return true; };
+        auto mine = [&](const Sent &p) { const Msg &m = g_shm->msgs[p.slot]; return m.state == 1 && m.uid == p.uid; };
+        auto all_taken = [&] { for (const Sent &p : posted) if (mine(p)) return false; return true; };
         if (!lk.wait(all_taken)) {
-            for (int s : posted) {
-                Msg &m = g_shm->msgs[s];
-                if (m.state != 1) continue;
+            for (const Sent &p : posted) {
+                Msg &m = g_shm->msgs[p.slot];
+                if (!mine(p)) continue;
                 fprintf(stderr, "mock rccl (ipc): rank %u: %s to rank %u never met its partner (timed out)\n", m.src, m.channel ? "send" : "all-gather piece", m.dst);
                 g_shm->seq_take[m.world][m.src][m.dst][m.channel]++;   // the receiver will not see this one any more
                 release(m);

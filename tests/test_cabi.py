@@ -56,6 +56,9 @@ def test_argument_validation_without_gpu(built):
     bad = lib.Config(64, 48, 300, 1, -1, 0, 0, 0)
     assert built.mi355_create(C.byref(bad), C.byref(h)) == lib.ERR_INVALID
     assert b"threshold" in built.mi355_last_error()
+    bad = lib.Config(64, 48, 20, 1, -1, 0, 0, 1)   # cfg.flags: no flag is defined (the experiment flags of rounds 2-4 are gone)
+    assert built.mi355_create(C.byref(bad), C.byref(h)) == lib.ERR_INVALID
+    assert b"flags" in built.mi355_last_error()
     bad = lib.Config(1920, 1080, 20, 1000, -1, 0, 0, 0)  # 1000 * 6.2 MB >= 2^32
     assert built.mi355_create(C.byref(bad), C.byref(h)) == lib.ERR_INVALID
     # max_batch = 1: the code log (two KiB chunks per tile) is the larger log; a frame within 1 KiB of 2^31 bytes would

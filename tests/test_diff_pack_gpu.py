@@ -604,3 +604,52 @@ def test_pipelined_batches_then_other_entry_points(po):
         client.synchronize()
         assert np.array_equal(client.get_state(), est)          # the client's frame == the server's state
         assert np.array_equal(core.get_state(), est)
+
+
+def test_options_change_the_schedule_never_the_result(po):
+    """mi355_set_option (include/mi355diff.h, "Options"): every combination of pipelining, split share, pack grid, dense
+    threshold and chain hint gives the oracle's stream for batches queued back to back on the core's own stream; values
+    outside an option's range, unknown options and non-zero cfg.flags are refused."""
+    w, h, T, K = 640, 360, 5, 3
+    n = 3 * w * h
+    base, frames = synth.webcam_stream(T * K, w, h, seed=91)
+    frames = np.ascontiguousarray(frames)
+    eo, exs, edf, est = po.diff_stream(frames, base)
+    d_fr = to_dev(frames)
+    combos = [{}, {lib.OPT_PIPELINE: 0}, {lib.OPT_SPLIT_PCT: 0}, {lib.OPT_SPLIT_PCT: 30}, {lib.OPT_SPLIT_PCT: 95},
+              {lib.OPT_PACK_BLOCKS: 0}, {lib.OPT_PACK_BLOCKS: 7}, {lib.OPT_PACK_BLOCKS: 4096, lib.OPT_SPLIT_PCT: 70},
+              {lib.OPT_DENSE_PCT: 0}, {lib.OPT_DENSE_PCT: 1}, {lib.OPT_CHAIN_HINT: 0, lib.OPT_DENSE_PCT: 100}]
+    per_frame = np.diff(eo.astype(np.int64))
+    for opts in combos:
+        with CUDACore(w, h, max_batch=T, sample_mat_data=base) as core:
+            for k, v in opts.items():
+                core.set_option(k, v)
+                assert core.get_option(k) == v
+            outs = [(torch.zeros(T + 1, dtype=torch.int32, device=DEV), torch.full((T * n,), -7, dtype=torch.int32, device=DEV),
+                     torch.zeros(T * n, dtype=torch.uint8, device=DEV)) for _ in range(K)]
+            torch.cuda.synchronize()
+            for k in range(K):   # no synchronisation between the batches
+                RawCore.diff_stream_batch(core, d_fr[k * T:(k + 1) * T], T, *outs[k], T * n)
+            core.synchronize()
+            assert np.array_equal(core.get_state(), est), opts
+            at = 0
+            for k in range(K):
+                cnt = per_frame[k * T:(k + 1) * T]
+                off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint32)
+                tot = int(off[-1])
+                assert np.array_equal(outs[k][0].cpu().numpy().view(np.uint32), off), (opts, k)
+                assert np.array_equal(outs[k][1][:tot].cpu().numpy(), exs[at:at + tot]), (opts, k)
+                assert np.array_equal(outs[k][2][:tot].cpu().numpy(), edf[at:at + tot]), (opts, k)
+                at += tot
+    with CUDACore(8, 8) as core:
+        assert core.get_option(lib.OPT_PIPELINE) == 1 and core.get_option(lib.OPT_SPLIT_PCT) == 50
+        assert core.get_option(lib.OPT_DENSE_PCT) == 40 and core.get_option(lib.OPT_CHAIN_HINT) == 1
+        assert core.get_option(lib.OPT_PACK_BLOCKS) == -1
+        for k, v in ((lib.OPT_PIPELINE, 2), (lib.OPT_SPLIT_PCT, 3), (lib.OPT_SPLIT_PCT, 96), (lib.OPT_DENSE_PCT, 101),
+                     (lib.OPT_CHAIN_HINT, -1), (lib.OPT_PACK_BLOCKS, -2), (99, 0), (0, 1)):
+            with pytest.raises(lib.Mi355Error):
+                core.set_option(k, v)
+    import ctypes as C
+    h_ = C.c_void_p()
+    cfg = lib.Config(8, 8, 20, 1, -1, 0, 0, 1)   # flags != 0: the experiment flags of rounds 2-4 are gone
+    assert lib.load().mi355_create(C.byref(cfg), C.byref(h_)) == lib.ERR_INVALID
