@@ -122,13 +122,11 @@ struct mi355_core {
     // Adaptive overlap: a batch whose expansion is longer than its pack kernel (dense input: a scene change, the synthetic
     // worst cases) loses by running beside the next batch's pack kernel (S0 pairs 0.313 ms one after the other, 0.35
     // overlapped).  The batch total (offsets[nframes]) of every own-stream batch is copied to pinned host memory behind its
-    // expansion; the next calls look at the latest total that HAS ARRIVED (hipEventQuery, no waiting) and run one batch after
-    // the other while more than dense_pct per cent of the bytes changed.  Results never depend on it, only the schedule.
-    static constexpr int kTotSlots = 4;
-    uint32_t *h_tot = nullptr;        // pinned, kTotSlots words
-    hipEvent_t tot_ev[kTotSlots] = {};
-    int tot_frames[kTotSlots] = {};
-    uint32_t tot_next = 0;
+    // expansion; the next calls look at the latest total that HAS ARRIVED (a word of pinned memory the index kernel stores, no
+    // waiting) and run one batch after the other while more than dense_pct per cent of the bytes changed.  Results never depend
+    // on it, only the schedule.
+    uint64_t *h_tot = nullptr;        // pinned: {entries of the latest own-stream batch whose index has run, its frames << 32},
+                                      // stored by that batch's index kernel itself (k_scan_groups, `note`)
     int dense_pct = 40;               // MI355_OPT_DENSE_PCT (0: never switch)
     bool dense = false;               // what the latest total that has arrived said
     bool filter_since_batch = false;  // a frame filter ran on this core since the last batch (use_device_filter)
@@ -274,11 +272,8 @@ int setup_pipeline(mi355_core *c) {
     ok = ok && hipMemset(s1.totals, 0, (2 * T + 2) * sizeof(uint32_t)) == hipSuccess;   // epoch 0 = never written; the ticket
     ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&c->main2, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&c->h_tot, mi355_core::kTotSlots * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
-    for (int i = 0; i < mi355_core::kTotSlots && ok; i++) {
-        c->h_tot[i] = 0;
-        ok = hipEventCreateWithFlags(&c->tot_ev[i], hipEventDisableTiming) == hipSuccess;
-    }
+    ok = ok && hipHostMalloc((void **)&c->h_tot, sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
+    if (ok) *c->h_tot = 0;
     for (int i = 0; i < mi355_core::kSets && ok; i++) {
         // device-scope release: these events only order kernels of this device against each other.  An event's default
         // is a SYSTEM-scope fence when it is recorded (caches written back and invalidated for the host's benefit),
@@ -331,13 +326,9 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     }
     if (pipelined && c->h_tot && c->dense_pct > 0 && c->dense_pct < 100) {
         // the latest batch total that has arrived: dense input -> this batch runs after the expansion of the one before
-        for (uint32_t k = 1; k <= (uint32_t)mi355_core::kTotSlots && k <= c->tot_next; k++) {
-            const uint32_t slot = (c->tot_next - k) % mi355_core::kTotSlots;
-            if (hipEventQuery(c->tot_ev[slot]) != hipSuccess) continue;
-            c->dense = (uint64_t)c->h_tot[slot] * 100u > (uint64_t)c->dense_pct * (uint64_t)c->tot_frames[slot] * c->n;
-            break;
-        }
-        if (c->dense) pipelined = false;   // (no total has arrived since the last look: what the last one said still holds)
+        const uint64_t note = __atomic_load_n(c->h_tot, __ATOMIC_RELAXED);   // one 64-bit word: never torn
+        if (note >> 32) c->dense = (note & 0xffffffffull) * 100u > (uint64_t)c->dense_pct * (note >> 32) * c->n;
+        if (c->dense) pipelined = false;   // (no total has arrived yet: what the last one said still holds)
     }
     if (!pipelined)
         if (int rc = use_device(c)) return rc;
@@ -434,8 +425,11 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     }
     if (tev) HIP_TRY(hipEventRecord(tev[2], tail));
     if (++c->scan_epoch == 0) c->scan_epoch = 1;
+    // (an own-stream batch leaves its total in pinned memory for the next calls' decisions -- stored by the index kernel
+    // itself: a copy + an event behind every batch cost config 3's chain 4 %, the event's system-scope fence included)
+    uint64_t *const note = own && c->h_tot && c->pipeline_ok && c->dense_pct > 0 && c->dense_pct < 100 ? c->h_tot : nullptr;
     HIP_TRY(launch_scan(ls.meta, ls.groff, (uint64_t *)ls.totals, c->ntiles, nframes, (uint32_t *)d_offsets,
-                        ls.totals + 2 * (size_t)c->cfg.max_batch, c->scan_epoch, tail));
+                        ls.totals + 2 * (size_t)c->cfg.max_batch, c->scan_epoch, note, tail));
     if (tev) HIP_TRY(hipEventRecord(tev[3], tail));
     ExpandArgs g{};
     g.rec = ls.rec;
@@ -454,13 +448,6 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     if (tev) {
         HIP_TRY(hipEventRecord(tev[4], tail));
         c->ev_count += 1;
-    }
-    if (own && c->h_tot && c->pipeline_ok && c->dense_pct > 0 && c->dense_pct < 100) {
-        const uint32_t slot = c->tot_next % mi355_core::kTotSlots;
-        HIP_TRY(hipMemcpyAsync(&c->h_tot[slot], (const uint32_t *)d_offsets + nframes, sizeof(uint32_t), hipMemcpyDeviceToHost, tail));
-        HIP_TRY(hipEventRecord(c->tot_ev[slot], tail));
-        c->tot_frames[slot] = nframes;
-        c->tot_next += 1;
     }
     if (pipelined) {
         HIP_TRY(hipEventRecord(ls.expanded, tail));
@@ -571,7 +558,6 @@ void mi355_destroy(mi355_core *c) {
         if (c->main2) { (void)hipStreamSynchronize(c->main2); (void)hipStreamDestroy(c->main2); }
         for (auto &e : c->packed2) if (e) (void)hipEventDestroy(e);
         for (auto &e : c->fork) if (e) (void)hipEventDestroy(e);
-        for (auto &e : c->tot_ev) if (e) (void)hipEventDestroy(e);
         if (c->h_tot) (void)hipHostFree(c->h_tot);
     }
     void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->codes, c->meta, c->groff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,

@@ -432,7 +432,7 @@ __device__ __forceinline__ uint32_t read_total(const uint64_t *slot, uint32_t ep
 // into offsets[0..T]: one launch and one dependent round trip less than a separate kernel.
 __global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t *roff, uint64_t *totals,
                                                      uint32_t ntiles, uint32_t ngroups, uint32_t *ticket,
-                                                     uint32_t epoch, uint32_t *offsets) {
+                                                     uint32_t epoch, uint32_t *offsets, uint64_t *note) {
     static_assert(kXTiles == 64, "one wave reduces one group");
     __builtin_amdgcn_s_setprio(3);   // pipelined batches: this short kernel gates the expansion; it must not queue for
                                      // issue slots behind the next batch's pack waves
@@ -509,15 +509,18 @@ __global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t
     if (threadIdx.x == 0) {
         offsets[nframes] = carry;
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the batch's total and its frames for the HOST's next scheduling decision (core.hip, adaptive overlap): one word of
+        // pinned memory, one store -- a hint, ordered against nothing
+        if (note) __hip_atomic_store(note, (uint64_t)carry | ((uint64_t)nframes << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
 uint32_t expand_groups(uint32_t ntiles) { return (ntiles + kXTiles - 1) / kXTiles; }
 
 hipError_t launch_scan(const uint4 *meta, uint32_t *roff, uint64_t *totals, uint32_t ntiles,
-                       int nframes, uint32_t *offsets, uint32_t *ticket, uint32_t epoch, hipStream_t s) {
+                       int nframes, uint32_t *offsets, uint32_t *ticket, uint32_t epoch, uint64_t *note, hipStream_t s) {
     hipLaunchKernelGGL(k_scan_groups, dim3(nframes), dim3(256), 0, s, meta, roff, totals, ntiles,
-                       expand_groups(ntiles), ticket, epoch, offsets);
+                       expand_groups(ntiles), ticket, epoch, offsets, note);
     return hipGetLastError();
 }
 

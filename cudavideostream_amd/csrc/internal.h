@@ -61,7 +61,8 @@ hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, bool pai
 uint32_t expand_groups(uint32_t ntiles);
 hipError_t launch_scan(const uint4 *meta, uint32_t *roff, uint64_t *totals /* [T] {total, epoch} */, uint32_t ntiles,
                        int nframes, uint32_t *offsets, uint32_t *ticket /* zero between launches */,
-                       uint32_t epoch /* != 0, different from the launch that last wrote `totals` */, hipStream_t s);
+                       uint32_t epoch /* != 0, different from the launch that last wrote `totals` */,
+                       uint64_t *note /* pinned host word for {batch total, frames << 32}, or nullptr */, hipStream_t s);
 hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s);
 
 // stream_ops.hip

@@ -154,9 +154,9 @@ int mi355_set_glyphs(mi355_core *core, const uint8_t *chars_px, int nglyphs, int
  * overlapped either: one kernel after the other measured faster for such chains (MI355_OPT_CHAIN_HINT 0: overlap
  * regardless).
  * The overlap is adaptive: a batch in which more than 40 % of the bytes changed (a scene change; MI355_OPT_DENSE_PCT) has an
- * expansion longer than its pack kernel and loses by running beside the next batch.  The library copies every own-stream
- * batch's total to pinned host memory behind its expansion and, without ever waiting for it, runs batches one after the
- * other while the latest total that has arrived says "dense".  Only the schedule depends on it, never a result.
+ * expansion longer than its pack kernel and loses by running beside the next batch.  The index kernel of every own-stream
+ * batch leaves the batch's total in a word of pinned host memory; the library, without ever waiting for it, runs batches
+ * one after the other while the latest total that has arrived says "dense".  Only the schedule depends on it, never a result.
  * Cache policy: the frames of a stream are read, and every output (d_xs, d_diff, d_wire; the visualiser frames of the
  * filters) is written, with non-temporal instructions -- each is touched once.  A consumer that reads the packed stream
  * right behind the batch (mi355_apply_*, the red map, the gather) reads it from memory, not from the caches. */
