@@ -13,7 +13,7 @@ say "== bench.py default"; timeout -k 10 600 python bench.py --steps 20 --warmup
 say "== bench.py sequential"; MI355_PIPELINE=0 timeout -k 10 400 python bench.py --steps 20 --warmup 5 --no-cpu --no-host-path --no-config5 > $O/bench_sequential.json 2>/dev/null; say "rc=$?"
 say "== bench.py 4K stream"; timeout -k 10 400 python bench.py --steps 20 --warmup 5 --width 3840 --height 2160 --batch 64 --no-cpu --no-host-path --no-filters --no-pair > $O/bench_4k.json 2>/dev/null; say "rc=$?"
 say "== bench.py 4K round-robin pairs"; timeout -k 10 400 python bench.py --steps 20 --warmup 5 --width 3840 --height 2160 --batch 64 --shard roundrobin --no-cpu --no-host-path --no-filters --no-pair > $O/bench_4k_roundrobin.json 2>/dev/null; say "rc=$?"
-say "== bench.py rehearsal, 4 ranks on the one GPU (1080p, 64-frame batches)"; timeout -k 10 400 python bench.py --gpus 4 --rehearse-on-one-gpu --batch 64 --steps 5 --warmup 2 --gather-every-steps 3 --no-cpu > $O/bench_rehearsal4.json 2> $O/bench_rehearsal4.err; say "rc=$?"
+say "== bench.py rehearsal, 4 ranks on the one GPU (1080p, 64-frame batches)"; timeout -k 10 400 python bench.py --gpus 4 --rehearse-on-one-gpu --batch 64 --steps 5 --warmup 2 --gather-every-steps 6 --no-cpu > $O/bench_rehearsal4.json 2> $O/bench_rehearsal4.err; say "rc=$?"
 say "== run_profile.sh r05"; bash profiles/run_profile.sh r05 5 > $O/run_profile.txt 2>&1; tail -25 $O/run_profile.txt >> $O/log.txt
 say "== filters"; bash profiles/run_profile_filters.sh r05 > $O/run_profile_filters.txt 2>&1; tail -25 $O/run_profile_filters.txt >> $O/log.txt
 say "== pair 1080p apart"; bash profiles/pmc_fw.sh pair1080apart --apart --batch 128 > $O/pmc_pair1080apart.txt 2>&1
