@@ -7,7 +7,8 @@
 //                 -DMI355_PAD=n      n extra vector instructions per frame and tile of the pack kernel
 //                 -DMI355_XWAVES=n   waves (= items) per workgroup of the expander
 // to price parts of the kernels (outputs of such builds are wrong by design; only their times matter).  Nothing else in
-// the library is switchable at build time, and nothing but the variables documented in include/mi355diff.h at run time.
+// the diff path is switchable at build time (filters.hip keeps one documented option, MI355_GRAY_FP64=0: the proven integer
+// form of the weighted gray), and nothing but what include/mi355diff.h documents ("Options") at run time.
 #ifndef MI355_LAB_H_
 #define MI355_LAB_H_
 namespace mi355 {
