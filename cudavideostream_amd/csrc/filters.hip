@@ -256,7 +256,7 @@ hipError_t launch_gray(const uint8_t *in, uint8_t *out, uint32_t npix, bool weig
 // workgroup, then 256 global atomics per 16384 pixels (integer adds: order-independent).  MODE 0 reads the gray
 // value replicated in a gray3 frame (every 3rd byte, server.cpp:104); MODE 1/2 read the COLOUR frame
 // and compute the gray value on the fly (fused chain: no gray frame is materialised).
-constexpr int kHistReplicas = 8;    // private copies of the 256 bins per wave (lane & 7)
+constexpr int kHistReplicas = 4;    // private copies of the 256 bins per wave (lane & 3): 16 KB of LDS per workgroup (round 5; 8: 4 % slower on webcam frames, 2: the same as 4)
 constexpr int kHistBlocks = 4;      // 16-pixel x 256-lane blocks per workgroup (16384 pixels)
 
 // gray1 != nullptr (MODE 1/2): the gray value of every pixel is also kept, one byte per pixel (frame f at
@@ -269,18 +269,20 @@ __global__ __launch_bounds__(256) void k_histogram(const uint8_t *img, uint32_t 
     img += (size_t)blockIdx.y * stride;
     hist += (size_t)blockIdx.y * 256;
     if (gray1) gray1 += (size_t)blockIdx.y * gray1_stride;
-    for (int i = threadIdx.x; i < 4 * kHistReplicas * 256; i += 256) (&bins[0][0])[i] = 0;
-    __syncthreads();
     int32_t *mine = bins[(threadIdx.x >> 6) * kHistReplicas + (threadIdx.x & (kHistReplicas - 1))];
     // the workgroup's kHistBlocks x 16 pixels per lane are all requested before the first is looked at (the
-    // conversions and LDS atomics of one block then run while the next blocks' bytes are on their way)
+    // conversions and LDS atomics of one block then run while the next blocks' bytes are on their way) -- and before
+    // the 32 KB of bins are cleared (round 5): the 32 LDS writes per lane and the barrier fall into the loads' flight time
     const uint32_t px0 = (blockIdx.x * kHistBlocks * 256u + threadIdx.x) * 16u;
     const bool whole = FAST && (blockIdx.x + 1u) * kHistBlocks * 256u * 16u <= npix;   // workgroup-uniform
-    if (whole) {
+    if (whole) {   // (workgroup-uniform: the barrier below is reached by all or none)
         Px16 p[kHistBlocks];
 #pragma unroll
         for (int it = 0; it < kHistBlocks; it++)
             p[it] = MODE != 0 ? load_px16_once(img + (size_t)(px0 + it * 4096u) * 3) : load_px16<true>(img + (size_t)(px0 + it * 4096u) * 3, 48);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int i = threadIdx.x; i < 4 * kHistReplicas * 256; i += 256) (&bins[0][0])[i] = 0;
+        __syncthreads();
 #pragma unroll
         for (int it = 0; it < kHistBlocks; it++) {
             uint32_t gw[4] = {0, 0, 0, 0};
@@ -296,6 +298,8 @@ __global__ __launch_bounds__(256) void k_histogram(const uint8_t *img, uint32_t 
                 *reinterpret_cast<uint4 *>(gray1 + px0 + it * 4096u) = make_uint4(gw[0], gw[1], gw[2], gw[3]);
         }
     } else {
+    for (int i = threadIdx.x; i < 4 * kHistReplicas * 256; i += 256) (&bins[0][0])[i] = 0;
+    __syncthreads();
 #pragma unroll 1
     for (int it = 0; it < kHistBlocks; it++) {
         const uint32_t lane_px = ((blockIdx.x * kHistBlocks + it) * 256u + threadIdx.x) * 16u;
