@@ -257,6 +257,7 @@ hipError_t launch_gray(const uint8_t *in, uint8_t *out, uint32_t npix, bool weig
 // value replicated in a gray3 frame (every 3rd byte, server.cpp:104); MODE 1/2 read the COLOUR frame
 // and compute the gray value on the fly (fused chain: no gray frame is materialised).
 constexpr int kHistReplicas = 4;    // private copies of the 256 bins per wave (lane & 3): 16 KB of LDS per workgroup (round 5; 8: 4 % slower on webcam frames, 2: the same as 4)
+constexpr int kHistRow = 257;       // words between two copies of the bins (not 256: see k_histogram)
 constexpr int kHistBlocks = 4;      // 16-pixel x 256-lane blocks per workgroup (16384 pixels)
 
 // gray1 != nullptr (MODE 1/2): the gray value of every pixel is also kept, one byte per pixel (frame f at
@@ -265,11 +266,14 @@ constexpr int kHistBlocks = 4;      // 16-pixel x 256-lane blocks per workgroup 
 template <int MODE /*0: gray3 in, 1: colour in + avg, 2: colour in + weighted*/, bool FAST>
 __global__ __launch_bounds__(256) void k_histogram(const uint8_t *img, uint32_t npix, int32_t *hist,
                                                    size_t stride, uint8_t *gray1, size_t gray1_stride) {
-    __shared__ int32_t bins[4 * kHistReplicas][256];
+    // a copy's 256 bins are kHistRow = 257 words apart: bin g of copy r lies in LDS bank (g + r) % 64, so the copies of ONE bin
+    // -- all that a flat frame touches -- are in different banks (with rows of 256 words they shared one, and flat frames
+    // took the pass 5.0 us instead of 2.8 however many copies there were: profiles/r05r_histogram_replicas.log)
+    __shared__ int32_t bins[4 * kHistReplicas * kHistRow];
     img += (size_t)blockIdx.y * stride;
     hist += (size_t)blockIdx.y * 256;
     if (gray1) gray1 += (size_t)blockIdx.y * gray1_stride;
-    int32_t *mine = bins[(threadIdx.x >> 6) * kHistReplicas + (threadIdx.x & (kHistReplicas - 1))];
+    int32_t *mine = bins + ((threadIdx.x >> 6) * kHistReplicas + (threadIdx.x & (kHistReplicas - 1))) * kHistRow;
     // the workgroup's kHistBlocks x 16 pixels per lane are all requested before the first is looked at (the
     // conversions and LDS atomics of one block then run while the next blocks' bytes are on their way) -- and before
     // the 32 KB of bins are cleared (round 5): the 32 LDS writes per lane and the barrier fall into the loads' flight time
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(256) void k_histogram(const uint8_t *img, uint32_t 
         for (int it = 0; it < kHistBlocks; it++)
             p[it] = MODE != 0 ? load_px16_once(img + (size_t)(px0 + it * 4096u) * 3) : load_px16<true>(img + (size_t)(px0 + it * 4096u) * 3, 48);
         __builtin_amdgcn_sched_barrier(0);
-        for (int i = threadIdx.x; i < 4 * kHistReplicas * 256; i += 256) (&bins[0][0])[i] = 0;
+        for (int i = threadIdx.x; i < 4 * kHistReplicas * kHistRow; i += 256) bins[i] = 0;
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < kHistBlocks; it++) {
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(256) void k_histogram(const uint8_t *img, uint32_t 
                 *reinterpret_cast<uint4 *>(gray1 + px0 + it * 4096u) = make_uint4(gw[0], gw[1], gw[2], gw[3]);
         }
     } else {
-    for (int i = threadIdx.x; i < 4 * kHistReplicas * 256; i += 256) (&bins[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < 4 * kHistReplicas * kHistRow; i += 256) bins[i] = 0;
     __syncthreads();
 #pragma unroll 1
     for (int it = 0; it < kHistBlocks; it++) {
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(256) void k_histogram(const uint8_t *img, uint32_t 
     __syncthreads();
     int v = 0;
 #pragma unroll
-    for (int r = 0; r < 4 * kHistReplicas; r++) v += bins[r][threadIdx.x];
+    for (int r = 0; r < 4 * kHistReplicas; r++) v += bins[r * kHistRow + threadIdx.x];
     if (v) atomicAdd(&hist[threadIdx.x], v);
 }
 
