@@ -618,8 +618,8 @@ __device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint32_
 // the two -- stretches).  Alone the kernel runs 8 waves per SIMD either way.
 constexpr uint32_t kWTiles = 16;             // tiles per item: one DPP row of lanes, a quarter of a scan group
 constexpr uint32_t kWStage = 1024;           // entries of the LDS stage = the most one tile can hold
-constexpr uint32_t kFList = 128;             // most multi-byte lanes of an item on the pair path (queued in 1 KiB of LDS)
-constexpr uint32_t kFStage = kWStage;        // most entries of an item on the pair path (10 bits of a queued lane's word)
+constexpr uint32_t kFList = 128;             // most multi-byte lanes of an item on the group path (queued in 1 KiB of LDS)
+constexpr uint32_t kFStage = kWStage;        // most entries of an item on the group path (10 bits of a queued lane's word)
 constexpr uint32_t kXLight = 4;   // lanes with more flagged bytes than this are expanded by 16 lanes
 constexpr int kXHeavyMax = 12;               // ... unless a round of 64 lanes holds more of them than this
 
