@@ -111,6 +111,7 @@ struct mi355_core {
     hipEvent_t side_done = nullptr;   // == the `expanded` event of the last pipelined batch, or null: nothing pending
     bool pipeline_ok = true;          // false: MI355_PIPELINE=0 / MI355_OPT_PIPELINE 0, or the second set could not be allocated
     int pack_blocks_opt = -1;         // MI355_OPT_PACK_BLOCKS (-1: the default, 4 workgroups per CU)
+    int median_rows = 0;              // MI355_OPT_MEDIAN_ROWS (0: chosen per launch)
     uint32_t k1_blocks = 0;           // pipelined batches: workgroups of the pack kernel (0 = one tile per wave)
     // pipelined batches packed by TWO launches (tiles [0, split) on the core's stream, the rest on `main2`): the two chains
     // of pack kernels drift apart, each one's kernel boundary (L2 write-back, event packets: 21-25 us) falls into the other's
@@ -636,6 +637,10 @@ int mi355_set_option(mi355_core *c, int option, int value) {
                 }
             }
             return MI355_OK;
+        case MI355_OPT_MEDIAN_ROWS:
+            if (value < 0 || value > 60 || value % 5) return fail(MI355_ERR_INVALID, "MI355_OPT_MEDIAN_ROWS: 0 (default) or 5, 10, .. 60");
+            c->median_rows = value;
+            return MI355_OK;
         default: return fail(MI355_ERR_INVALID, "unknown option");
     }
 }
@@ -648,6 +653,7 @@ int mi355_get_option(mi355_core *c, int option, int *value) {
         case MI355_OPT_DENSE_PCT: *value = c->dense_pct; return MI355_OK;
         case MI355_OPT_CHAIN_HINT: *value = c->chain_hint ? 1 : 0; return MI355_OK;
         case MI355_OPT_PACK_BLOCKS: *value = c->pack_blocks_opt; return MI355_OK;
+        case MI355_OPT_MEDIAN_ROWS: *value = c->median_rows; return MI355_OK;
         default: return fail(MI355_ERR_INVALID, "unknown option");
     }
 }
@@ -888,7 +894,7 @@ int mi355_median5x5(mi355_core *c, const void *d_in, void *d_out) {
     if (!c || !d_in || !d_out) return fail(MI355_ERR_INVALID, "null argument");
     if (d_in == d_out) return fail(MI355_ERR_INVALID, "median is not in-place");
     if (int rc = use_device_filter(c)) return rc;
-    HIP_TRY(launch_median5x5((const uint8_t *)d_in, (uint8_t *)d_out, c->cfg.width, c->cfg.height,
+    HIP_TRY(launch_median5x5((const uint8_t *)d_in, (uint8_t *)d_out, c->cfg.width, c->cfg.height, c->median_rows,
                              FrameBatch{c->n, 1}, c->stream));
     return MI355_OK;
 }
@@ -923,7 +929,7 @@ int mi355_filter_batch(mi355_core *c, int op, const void *d_in, const void *d_in
         case MI355_OP_HEAT_MAP: HIP_TRY(launch_heat_map(in, in2, out, npix, c->lut, fb, c->stream)); break;
         case MI355_OP_RED_DENSE: HIP_TRY(launch_red_dense(in, in2, out, npix, c->cfg.threshold, fb, c->stream)); break;
         case MI355_OP_CONV3X3: HIP_TRY(launch_conv3x3(in, out, c->cfg.width, c->cfg.height, c->k9, c->k9_sym, fb, c->stream)); break;
-        case MI355_OP_MEDIAN5X5: HIP_TRY(launch_median5x5(in, out, c->cfg.width, c->cfg.height, fb, c->stream)); break;
+        case MI355_OP_MEDIAN5X5: HIP_TRY(launch_median5x5(in, out, c->cfg.width, c->cfg.height, c->median_rows, fb, c->stream)); break;
         default: return fail(MI355_ERR_INVALID, "unknown filter op");
     }
     return MI355_OK;

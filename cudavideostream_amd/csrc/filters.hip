@@ -1176,8 +1176,183 @@ __global__ __launch_bounds__(256) void k_median5x5(const uint8_t *in, uint8_t *o
     }
 }
 
-hipError_t launch_median5x5(const uint8_t *in, uint8_t *out, int w, int h, FrameBatch fb, hipStream_t s) {
+// k_median5x5_strip (rows a multiple of 8 bytes, 8-byte aligned frames; k_median5x5 above is the form for every other
+// geometry).  Round 5: the tile kernel read 25 single bytes from LDS per output and ran the 99-exchange network on one
+// output per instruction: 35 us per 1080p frame.  This one
+//   * computes TWO outputs per instruction: a register holds the same byte position of two row bands of the frame
+//     (rows y and y + bandrows) as two 16-bit halves, and every exchange is v_pk_min_u16 + v_pk_max_u16;
+//   * sorts every COLUMN of five rows once (18 instructions) and shares it between the five outputs whose windows
+//     contain it; what is left per output is the 13th smallest of 25 values in five ascending groups: the program of
+//     csrc/median_net.h (tools/median_net/search.py derives it from a sorter by pruning and proves it on all 7776
+//     zero-one inputs with sorted columns);
+//   * has no LDS, no barriers and no edge code: a lane owns 8 bytes x 2 bands, walks them top to bottom with a ring
+//     of five rows in registers, and takes the sorted columns left and right of its own (the windows reach 6 bytes =
+//     two pixels either side) from the neighbour lanes with DPP moves.  Lanes 0 and 63 of a wave only supply their
+//     columns (a wave stores 62 strips, neighbouring waves overlap by two); rows and strips outside the image are
+//     reads beyond the buffer descriptor's records, i.e. zeros (v3.cu:61-69), and stores there are dropped.
+typedef _Float16 med_u16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t med_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int kMedStripLanes = 62;   // strips a wave stores
+
+__device__ __forceinline__ med_u16x2 med_min(med_u16x2 a, med_u16x2 b) { return __builtin_elementwise_minimum(a, b); }
+__device__ __forceinline__ med_u16x2 med_max(med_u16x2 a, med_u16x2 b) { return __builtin_elementwise_maximum(a, b); }
+__device__ __forceinline__ med_u16x2 med_from(uint32_t v) { return __builtin_bit_cast(med_u16x2, v); }
+__device__ __forceinline__ uint32_t med_bits(med_u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+#include "median_net.h"
+// the 13th smallest of the 25 values of five ascending columns
+__device__ __forceinline__ med_u16x2 median_of_sorted_columns(const med_u16x2 (&c0)[5], const med_u16x2 (&c1)[5],
+                                                              const med_u16x2 (&c2)[5], const med_u16x2 (&c3)[5],
+                                                              const med_u16x2 (&c4)[5]) {
+#define MEDNET_IN(col, rank) (col == 0 ? c0[rank] : col == 1 ? c1[rank] : col == 2 ? c2[rank] : col == 3 ? c3[rank] : c4[rank])
+#define MEDNET_MIN(d, a, b) const med_u16x2 d = med_min(a, b);
+#define MEDNET_MAX(d, a, b) const med_u16x2 d = med_max(a, b);
+#define MEDNET_OUT(x) return x;
+    MEDNET_BODY
+#undef MEDNET_IN
+#undef MEDNET_MIN
+#undef MEDNET_MAX
+#undef MEDNET_OUT
+}
+
+#define MED_CE(a, b) { const med_u16x2 lo_ = med_min(s[a], s[b]); s[b] = med_max(s[a], s[b]); s[a] = lo_; }
+__device__ __forceinline__ void med_sort5(med_u16x2 (&s)[5]) {   // 9 exchanges
+    MED_CE(0, 1) MED_CE(3, 4) MED_CE(2, 4) MED_CE(2, 3) MED_CE(0, 3) MED_CE(0, 2) MED_CE(1, 4) MED_CE(1, 3) MED_CE(1, 2)
+}
+#undef MED_CE
+
+__global__ __launch_bounds__(64)
+void k_median5x5_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, int bandrows, int waves_per_row, size_t stride) {
+    constexpr uint32_t kOut = 0x80000000u;   // beyond every frame (mi355_create: N < 2^31); + a band's rows it does not wrap
+    const uint32_t lane = threadIdx.x;
+    const uint32_t frame_bytes = (uint32_t)rowbytes * (uint32_t)h;
+    const __amdgpu_buffer_rsrc_t src = conv_rsrc(in + (size_t)blockIdx.z * stride, frame_bytes);
+    uint8_t *dst_base = out + (size_t)blockIdx.z * stride;
+    const uint32_t strips = (uint32_t)rowbytes / 8u;
+    const uint32_t pair = blockIdx.x / (uint32_t)waves_per_row, wx = blockIdx.x - pair * (uint32_t)waves_per_row;
+    // lane l of wave wx is strip 62 wx - 1 + l: lanes 1..62 store, lanes 0 and 63 hold the strips of the neighbour waves
+    const int strip = (int)(wx * kMedStripLanes + lane) - 1;
+    const bool inside = strip >= 0 && (uint32_t)strip < strips;
+    // band A = rows ya .. ya + bandrows - 1, band B the bandrows rows below it; the walk starts two rows above a band.
+    // Offsets are modulo 2^32: a row above the image is a huge offset (no records there: zeros) until the walk reaches row 0.
+    const int ya = (int)pair * 2 * bandrows;
+    const uint32_t colA = inside ? (uint32_t)((ya - 2) * rowbytes) + (uint32_t)strip * 8u : kOut;
+    const uint32_t colB = inside ? colA + (uint32_t)(bandrows * rowbytes) : kOut;
+    const bool stores = inside && lane >= 1u && lane <= (uint32_t)kMedStripLanes;
+    const uint32_t outA = stores ? colA : kOut, outB = stores ? colB : kOut;
+
+    struct Raw { med_u32x2 a, b; };
+    auto load_row = [&](int i) {   // row ya - 2 + i of band A, the same row of band B
+        Raw v;
+        v.a = __builtin_bit_cast(med_u32x2, __builtin_amdgcn_raw_buffer_load_b64(src, colA + (uint32_t)i * (uint32_t)rowbytes, 0, 0));
+        v.b = __builtin_bit_cast(med_u32x2, __builtin_amdgcn_raw_buffer_load_b64(src, colB + (uint32_t)i * (uint32_t)rowbytes, 0, 0));
+        return v;
+    };
+    // byte q of band A in the low half, of band B in the high half
+    auto unpack = [&](const Raw &v, med_u16x2 (&p)[8]) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t sel = 0x0c000c00u | (uint32_t)(q & 3) | ((uint32_t)(4 + (q & 3)) << 16);
+            p[q] = med_from(__builtin_amdgcn_perm(q < 4 ? v.b.x : v.b.y, q < 4 ? v.a.x : v.a.y, sel) | 0x04000400u);
+        }
+    };
+
+    med_u16x2 ring[5][8];   // the five rows around the output row, in the order they arrived modulo 5 (a sort does not care)
+    Raw raw;
+    // One output row: `raw` (row k + 4 of the walk) completes the five rows, row k + 5 is requested, the columns are sorted
+    // and the 8 positions x 2 bands are selected and stored.
+    auto step = [&](int k, med_u16x2 (&fresh)[8]) {
+        unpack(raw, fresh);
+        __builtin_amdgcn_sched_barrier(0);
+        raw = load_row(k + 5);
+        __builtin_amdgcn_sched_barrier(0);
+        med_u16x2 s[8][5];   // the sorted columns of the lane's own positions 0 .. 7
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+#pragma unroll
+            for (int r = 0; r < 5; r++) s[q][r] = ring[r][q];
+            med_sort5(s[q]);
+        }
+        uint32_t m[8];
+        // v3.cu:79-88: the window of position q is the columns q - 6, q - 3, q, q + 3, q + 6 (one colour channel).  The
+        // three channels in turn (fewer columns alive at once): positions c - 6, c - 3, .. <= 13, of which the ones below 0
+        // are the left neighbour's positions + 8 and the ones above 7 the right neighbour's positions - 8.
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            med_u16x2 col[7][5];
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                const int pos = c - 6 + 3 * j;
+                if (pos > 13) continue;
+#pragma unroll
+                for (int r = 0; r < 5; r++) {
+                    if (pos < 0)
+                        col[j][r] = med_from((uint32_t)__builtin_amdgcn_update_dpp(0, (int)med_bits(s[pos + 8 < 8 ? pos + 8 : 0][r]), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
+                    else if (pos > 7)
+                        col[j][r] = med_from((uint32_t)__builtin_amdgcn_update_dpp(0, (int)med_bits(s[pos - 8 >= 0 ? pos - 8 : 0][r]), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
+                    else
+                        col[j][r] = s[pos][r];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const int q = c + 3 * i;
+                if (q > 7) continue;
+                m[q] = med_bits(median_of_sorted_columns(col[i], col[i + 1], col[i + 2], col[i + 3], col[i + 4]));
+                // one output at a time (the registers of one selection program, not of three): the empty statement makes the
+                // result exist HERE -- a value nobody reads until the row is stored is otherwise placed behind every barrier
+                asm volatile("" : "+v"(m[q]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // m[q] = (band A's byte q, 0, band B's byte q, 0)
+        const uint32_t t01 = __builtin_amdgcn_perm(m[1], m[0], 0x06020400u), t23 = __builtin_amdgcn_perm(m[3], m[2], 0x06020400u);
+        const uint32_t t45 = __builtin_amdgcn_perm(m[5], m[4], 0x06020400u), t67 = __builtin_amdgcn_perm(m[7], m[6], 0x06020400u);
+        const med_u32x2 oa = {__builtin_amdgcn_perm(t23, t01, 0x05040100u), __builtin_amdgcn_perm(t67, t45, 0x05040100u)};
+        const med_u32x2 ob = {__builtin_amdgcn_perm(t23, t01, 0x07060302u), __builtin_amdgcn_perm(t67, t45, 0x07060302u)};
+        // (no branch around the stores of the steps that round a band up to whole groups of five: a descriptor without
+        // records drops them; rows below the image are beyond the records by themselves)
+        const __amdgpu_buffer_rsrc_t d = conv_rsrc(dst_base, k < bandrows ? frame_bytes : 0u);
+        const uint32_t rowoff = (uint32_t)(k + 2) * (uint32_t)rowbytes;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(med_u32x2, oa), d, outA + rowoff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(med_u32x2, ob), d, outB + rowoff, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        raw = load_row(i);
+        unpack(raw, ring[i]);
+    }
+    raw = load_row(4);
+    for (int k = 0; k < bandrows; k += 5) {
+        step(k, ring[4]);
+        step(k + 1, ring[0]);
+        step(k + 2, ring[1]);
+        step(k + 3, ring[2]);
+        step(k + 4, ring[3]);
+    }
+}
+
+// rows per band of the strip kernel: whole groups of five; bands long enough that the four rows read above and below one
+// are few (40: + 10 %), short enough that a small batch still makes a few thousand waves
+static int median_bandrows(int h, int waves_per_row, int nframes) {
+    int rows = 40;
+    while (rows > 10 && (long)((h + 2 * rows - 1) / (2 * rows)) * waves_per_row * nframes < 4096) rows -= 5;
+    return rows;
+}
+
+hipError_t launch_median5x5(const uint8_t *in, uint8_t *out, int w, int h, int rows_per_band, FrameBatch fb, hipStream_t s) {
     if (w <= 0 || h <= 0 || fb.nframes <= 0) return hipSuccess;
+    const size_t rowbytes = (size_t)w * 3;
+    if (rowbytes % 8 == 0 && ((uintptr_t)in & 7u) == 0 && ((uintptr_t)out & 7u) == 0 && fb.stride % 8 == 0 && rowbytes < (1u << 24)) {
+        const int strips = (int)(rowbytes / 8), waves_per_row = (strips + kMedStripLanes - 1) / kMedStripLanes;
+        const int bandrows = rows_per_band > 0 ? rows_per_band : median_bandrows(h, waves_per_row, fb.nframes);
+        const int pairs = (h + 2 * bandrows - 1) / (2 * bandrows);
+        const dim3 grid((unsigned)(pairs * waves_per_row), 1, (unsigned)fb.nframes);
+        hipLaunchKernelGGL(k_median5x5_strip, grid, dim3(64), 0, s, in, out, (int)rowbytes, h, bandrows, waves_per_row, fb.stride);
+        return hipGetLastError();
+    }
     const dim3 grid((w + kMedTW - 1) / kMedTW, (h + kMedTR - 1) / kMedTR, (unsigned)fb.nframes);
     hipLaunchKernelGGL(k_median5x5, grid, dim3(256), 0, s, in, out, w, h, fb.stride);
     return hipGetLastError();

@@ -116,7 +116,8 @@ hipError_t launch_conv3x3(const uint8_t *in, uint8_t *out, int w, int h, const f
                           FrameBatch fb, hipStream_t s);
 hipError_t launch_conv_kxk(const uint8_t *in, uint8_t *out, int w, int h, const float *kk /* device, K*K */, int K,
                            FrameBatch fb, hipStream_t s);
-hipError_t launch_median5x5(const uint8_t *in, uint8_t *out, int w, int h, FrameBatch fb, hipStream_t s);
+hipError_t launch_median5x5(const uint8_t *in, uint8_t *out, int w, int h, int rows_per_band /* 0: chosen here */, FrameBatch fb,
+                            hipStream_t s);
 hipError_t launch_blit_glyph(uint8_t *frame, const uint8_t *glyph, int glyph_h, int glyph_wbytes,
                              int x_off_bytes, int frame_wbytes, int frame_h, hipStream_t s);
 

@@ -21,7 +21,7 @@ VIS_NONE, VIS_HEAT, VIS_RED, VIS_RED_OVERLAP, VIS_GRAY, VIS_BINARIZE = range(6)
 (OP_GRAY_AVG, OP_GRAY_WEIGHTED, OP_BINARIZE, OP_GRAY_AVG_BINARIZE, OP_GRAY_WEIGHTED_BINARIZE, OP_HEAT_MAP,
  OP_RED_DENSE, OP_CONV3X3, OP_MEDIAN5X5) = range(1, 10)
 
-OPT_PIPELINE, OPT_SPLIT_PCT, OPT_DENSE_PCT, OPT_CHAIN_HINT, OPT_PACK_BLOCKS = range(1, 6)   # MI355_OPT_*
+OPT_PIPELINE, OPT_SPLIT_PCT, OPT_DENSE_PCT, OPT_CHAIN_HINT, OPT_PACK_BLOCKS, OPT_MEDIAN_ROWS = range(1, 7)   # MI355_OPT_*
 
 
 class Config(C.Structure):

@@ -220,6 +220,35 @@ def test_median5x5(po, w, h):
             assert (got[t, n:] == 0).all()
 
 
+@pytest.mark.parametrize("w,h", [(8, 1), (8, 7), (16, 21), (24, 3), (168, 23), (336, 41), (64, 100), (176, 61)])
+def test_median5x5_strip_kernel(po, w, h):
+    """Rows that are a multiple of 8 bytes take the column-strip kernel (two row bands per register, shared column sorts,
+    the selection program of csrc/median_net.h): one strip wave (w = 8: three strips beside the two lanes that only
+    supply columns), a row that ends one strip into the second wave (168 pixels = 63 strips) and two into the third
+    (336), heights below, at and beyond one and two bands for every band length the option allows -- the band pairing,
+    the steps that round a band up to five rows and the rows below the image.  Saturated frames see the zero padding
+    on every border; every byte value occurs."""
+    rng = np.random.default_rng(31 * w + h)
+    n = 3 * w * h
+    ramp = (np.arange(n, dtype=np.int64) * 7 % 256).astype(np.uint8)
+    for rows in (0, 5, 10, 20, 25, 40, 60):
+        for img in (rng.integers(0, 256, n, dtype=np.uint8), np.full(n, 255, np.uint8), ramp):
+            with CUDACore(w, h) as core:
+                core.set_option(lib.OPT_MEDIAN_ROWS, rows)
+                d_o = dev_out(n)
+                core.median5x5(to_dev(img), d_o); core.synchronize()
+                assert np.array_equal(d_o.cpu().numpy(), po.median5x5(img, w, h)), rows
+    with CUDACore(w, h, max_batch=5) as core:       # batched, frame stride larger than the frame, guard bytes untouched
+        frames = rng.integers(0, 256, (5, n + 24), dtype=np.uint8)
+        d_in, d_out = to_dev(frames), torch.full((5, n + 24), 7, dtype=torch.uint8, device=DEV)
+        core.filter_batch(lib.OP_MEDIAN5X5, d_in, d_out, 5, stride=n + 24)
+        core.synchronize()
+        got = d_out.cpu().numpy()
+        for t in range(5):
+            assert np.array_equal(got[t, :n], po.median5x5(frames[t, :n], w, h))
+            assert (got[t, n:] == 7).all()
+
+
 @pytest.mark.parametrize("w,h", [(16, 30), (65, 17), (352, 95), (7, 5)])
 def test_conv3x3_sharpen_and_edge_kernels_saturate_the_same_way(po, w, h):
     """Negative taps and sums above 255: the column-strip kernel (row bytes a multiple of 16) and the general
