@@ -1298,7 +1298,10 @@ void k_median5x5_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, int
             for (int i = 0; i < 3; i++) {
                 const int q = c + 3 * i;
                 if (q > 7) continue;
-                m[q] = med_bits(median_of_sorted_columns(col[i], col[i + 1], col[i + 2], col[i + 3], col[i + 4]));
+                // the channel's windows col[0..4], col[1..5], col[2..6] as (what they have in common; their own two columns):
+                // the selection program reads its first three columns first, and what it computes from them alone is the
+                // same expression in all three calls -- computed once (tools/median_net/anneal.cpp, SHARE)
+                m[q] = med_bits(median_of_sorted_columns(col[2], col[3], col[4], col[i == 2 ? 5 : i], col[i == 0 ? 1 : i + 4]));
                 // one output at a time (the registers of one selection program, not of three): the empty statement makes the
                 // result exist HERE -- a value nobody reads until the row is stored is otherwise placed behind every barrier
                 asm volatile("" : "+v"(m[q]));
@@ -1335,10 +1338,11 @@ void k_median5x5_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, int
 }
 
 // rows per band of the strip kernel: whole groups of five; bands long enough that the four rows read above and below one
-// are few (40: + 10 %), short enough that a small batch still makes a few thousand waves
+// are few (40: + 10 % of loads, no arithmetic), short enough that a small batch still makes a few thousand waves (one frame:
+// 5 rows, 1296 waves at 1080p)
 static int median_bandrows(int h, int waves_per_row, int nframes) {
     int rows = 40;
-    while (rows > 10 && (long)((h + 2 * rows - 1) / (2 * rows)) * waves_per_row * nframes < 4096) rows -= 5;
+    while (rows > 5 && (long)((h + 2 * rows - 1) / (2 * rows)) * waves_per_row * nframes < 4096) rows -= 5;
     return rows;
 }
 

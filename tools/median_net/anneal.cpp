@@ -6,7 +6,15 @@
 // absorbed another one.  Moves: redirect the readers of an operation to an earlier wire; give an operation other
 // operands; insert a fresh operation and let a later one read it.  Accepts equal cost always, worse cost with a small
 // probability.  Prints the best program in the same format.
-//   g++ -O2 -std=c++17 -o anneal anneal.cpp && ./anneal SEED SECONDS < start.txt > best.txt
+//
+// SHARE = K > 1: the kernel computes K neighbouring windows of one colour channel in a lane; they have the columns 0, 1, 2
+// of the program in common and differ in the columns 3, 4 (for the windows P0..P4, P1..P5, P2..P6 of seven columns:
+// common P2 P3 P4; own P0 P1 / P1 P5 / P5 P6 -- the median does not care which column is which).  An operation that reads
+// only common columns is computed once for the K windows (the compiler merges the identical expressions), so it costs
+// 1 / K; the cost minimised is K x (instructions that depend on column 3 or 4) + (instructions that do not), and a shared
+// operation never folds into a private reader (it has K of them).
+// (SHARE = 2, NPRIV = 1: two windows P0..P4, P1..P5 of six columns with four columns in common.)
+//   g++ -O2 -std=c++17 -o anneal anneal.cpp && ./anneal SEED SECONDS [TEMP [SHARE [NPRIV]]] < start.txt > best.txt
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
@@ -79,9 +87,13 @@ static Prog clean(const Prog &p, std::vector<Bits> &v) {
     return q;
 }
 
+static int SHARE = 1, NPRIV = 2;
 // instructions after fusing: an op with exactly one reader of the same kind is absorbed by it if that reader is free
 static int cost(const Prog &p) {
     const int n = (int)p.ops.size();
+    std::vector<char> priv(25 + n, 0);
+    for (int i = 5 * (5 - NPRIV); i < 25; i++) priv[i] = 1;
+    for (int i = 0; i < n; i++) priv[25 + i] = priv[p.ops[i].a] | priv[p.ops[i].b];
     std::vector<int> uses(25 + n, 0);
     for (const Op &o : p.ops) { uses[o.a]++; uses[o.b]++; }
     uses[p.out] += 2;
@@ -89,12 +101,15 @@ static int cost(const Prog &p) {
     int c = 0;
     for (int i = n - 1; i >= 0; i--) {   // readers first
         if (absorbed[i]) continue;       // it is part of its reader
-        c++;
+        c += (SHARE > 1 && priv[25 + i]) ? SHARE : 1;
         const Op &o = p.ops[i];
         // absorb one operand op of the same kind with a single use (which may itself not absorb: it has become part of i,
         // whose three inputs are then full)
         for (int w : {o.a, o.b})
-            if (w >= 25 && uses[w] == 1 && p.ops[w - 25].k == o.k && o.a != o.b) { absorbed[w - 25] = 1; break; }
+            if (w >= 25 && uses[w] == 1 && p.ops[w - 25].k == o.k && o.a != o.b && (SHARE == 1 || priv[w] == priv[25 + i])) {
+                absorbed[w - 25] = 1;
+                break;
+            }
     }
     return c;
 }
@@ -104,7 +119,10 @@ static bool ok(const Prog &p, std::vector<Bits> &v) { eval(p, v); return eq(v[p.
 int main(int argc, char **argv) {
     const unsigned seed = argc > 1 ? atoi(argv[1]) : 1;
     const double seconds = argc > 2 ? atof(argv[2]) : 60;
-    const double temp = argc > 3 ? atof(argv[3]) : 0.02;   // probability of accepting +1
+    const double temp = argc > 3 ? atof(argv[3]) : 0.02;   // probability of accepting a slightly worse program
+    SHARE = argc > 4 ? atoi(argv[4]) : 1;
+    NPRIV = argc > 5 ? atoi(argv[5]) : 2;    // the last NPRIV columns are a window's own (2 with K = 3 windows, 1 with K = 2)
+    if (NPRIV < 1 || NPRIV > 4 || SHARE < 1) return 2;
     init_cases();
     Prog p;
     char word[16]; int a, b, c;
@@ -115,6 +133,7 @@ int main(int argc, char **argv) {
         p.ops.push_back({c, a, b});
     }
     std::vector<Bits> v;
+    if (p.ops.empty()) { fprintf(stderr, "no program on stdin\n"); return 2; }
     if (!ok(p, v)) { fprintf(stderr, "start program is wrong\n"); return 1; }
     p = clean(p, v);
     std::mt19937_64 rng(seed);
@@ -153,7 +172,7 @@ int main(int argc, char **argv) {
         if (!ok(q, v)) continue;
         q = clean(q, v);
         const int cq = cost(q);
-        if (cq <= ccur || (cq == ccur + 1 && (rng() % 10000) < temp * 10000)) {
+        if (cq <= ccur || (cq <= ccur + SHARE && (rng() % 10000) < temp * 10000)) {
             p = q; ccur = cq;
             if (cq < cbest) {
                 cbest = cq; best = q;

@@ -263,6 +263,8 @@ def main():
               % (len(p.ops), fused_cost(p), depth(p), NCASE))
         if a.emit:
             emit(p, a.emit)
+        if a.dump:
+            dump(p, a.dump)
         return
     rng = random.Random(a.seed)
     best = None
