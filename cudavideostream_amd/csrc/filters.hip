@@ -1222,20 +1222,25 @@ __device__ __forceinline__ void med_sort5(med_u16x2 (&s)[5]) {   // 9 exchanges
 #undef MED_CE
 
 __global__ __launch_bounds__(64)
-void k_median5x5_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, int bandrows, int waves_per_row, size_t stride) {
+void k_median5x5_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, int bandrows, int npairs, size_t stride) {
     constexpr uint32_t kOut = 0x80000000u;   // beyond every frame (mi355_create: N < 2^31); + a band's rows it does not wrap
     const uint32_t lane = threadIdx.x;
     const uint32_t frame_bytes = (uint32_t)rowbytes * (uint32_t)h;
     const __amdgpu_buffer_rsrc_t src = conv_rsrc(in + (size_t)blockIdx.z * stride, frame_bytes);
     uint8_t *dst_base = out + (size_t)blockIdx.z * stride;
     const uint32_t strips = (uint32_t)rowbytes / 8u;
-    const uint32_t pair = blockIdx.x / (uint32_t)waves_per_row, wx = blockIdx.x - pair * (uint32_t)waves_per_row;
-    // lane l of wave wx is strip 62 wx - 1 + l: lanes 1..62 store, lanes 0 and 63 hold the strips of the neighbour waves
-    const int strip = (int)(wx * kMedStripLanes + lane) - 1;
-    const bool inside = strip >= 0 && (uint32_t)strip < strips;
+    // The frame's (pair of bands, strip) places are dealt to the lanes in one running number u, every pair of bands with
+    // one empty place in front of its first strip and one behind its last (strips -1 and `strips`: lanes whose loads
+    // find no records, i.e. the zero columns left and right of the image).  Lane l of wave w is place 62 w - 1 + l:
+    // lanes 1..62 store, lanes 0 and 63 repeat the neighbour waves' places 62 and 1 and only supply their columns.
+    const int u = (int)(blockIdx.x * kMedStripLanes + lane) - 1;
+    const int per_pair = (int)strips + 2;
+    const int pair = u >= 0 ? u / per_pair : 0;
+    const int strip = u - pair * per_pair - 1;
+    const bool inside = u >= 0 && pair < npairs && strip >= 0 && (uint32_t)strip < strips;
     // band A = rows ya .. ya + bandrows - 1, band B the bandrows rows below it; the walk starts two rows above a band.
     // Offsets are modulo 2^32: a row above the image is a huge offset (no records there: zeros) until the walk reaches row 0.
-    const int ya = (int)pair * 2 * bandrows;
+    const int ya = pair * 2 * bandrows;
     const uint32_t colA = inside ? (uint32_t)((ya - 2) * rowbytes) + (uint32_t)strip * 8u : kOut;
     const uint32_t colB = inside ? colA + (uint32_t)(bandrows * rowbytes) : kOut;
     const bool stores = inside && lane >= 1u && lane <= (uint32_t)kMedStripLanes;
@@ -1337,24 +1342,31 @@ void k_median5x5_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, int
     }
 }
 
-// rows per band of the strip kernel: whole groups of five; bands long enough that the four rows read above and below one
-// are few (40: + 10 % of loads, no arithmetic), short enough that a small batch still makes a few thousand waves (one frame:
-// 5 rows, 1296 waves at 1080p)
-static int median_bandrows(int h, int waves_per_row, int nframes) {
-    int rows = 40;
-    while (rows > 5 && (long)((h + 2 * rows - 1) / (2 * rows)) * waves_per_row * nframes < 4096) rows -= 5;
-    return rows;
+// rows per band of the strip kernel: whole groups of five.  A wave walks a PAIR of bands, so the rows walked per strip are
+// pairs x rows >= h / 2: the band length that wastes least of the last pair wins (1080 rows: 45 or 60, twelve or nine
+// full pairs; 40 would walk 14 x 40 = 560 rows for 540), as long as the launch still has a few thousand waves; among
+// equals the longer band (a band reads four rows more than it writes).  One frame: 5 rows, 1260 waves at 1080p.
+static int median_bandrows(int h, int strips, int nframes) {
+    int best = 5;
+    long best_rows = -1;
+    for (int rows = 5; rows <= 60; rows += 5) {
+        const long pairs = (h + 2 * rows - 1) / (2 * rows);
+        const long waves = (pairs * (strips + 2) + kMedStripLanes - 1) / kMedStripLanes * nframes;
+        if (rows > 5 && waves < 4096) break;
+        if (best_rows < 0 || pairs * rows <= best_rows) { best = rows; best_rows = pairs * rows; }
+    }
+    return best;
 }
 
 hipError_t launch_median5x5(const uint8_t *in, uint8_t *out, int w, int h, int rows_per_band, FrameBatch fb, hipStream_t s) {
     if (w <= 0 || h <= 0 || fb.nframes <= 0) return hipSuccess;
     const size_t rowbytes = (size_t)w * 3;
     if (rowbytes % 8 == 0 && ((uintptr_t)in & 7u) == 0 && ((uintptr_t)out & 7u) == 0 && fb.stride % 8 == 0 && rowbytes < (1u << 24)) {
-        const int strips = (int)(rowbytes / 8), waves_per_row = (strips + kMedStripLanes - 1) / kMedStripLanes;
-        const int bandrows = rows_per_band > 0 ? rows_per_band : median_bandrows(h, waves_per_row, fb.nframes);
+        const int strips = (int)(rowbytes / 8);
+        const int bandrows = rows_per_band > 0 ? rows_per_band : median_bandrows(h, strips, fb.nframes);
         const int pairs = (h + 2 * bandrows - 1) / (2 * bandrows);
-        const dim3 grid((unsigned)(pairs * waves_per_row), 1, (unsigned)fb.nframes);
-        hipLaunchKernelGGL(k_median5x5_strip, grid, dim3(64), 0, s, in, out, (int)rowbytes, h, bandrows, waves_per_row, fb.stride);
+        const dim3 grid((unsigned)(((long)pairs * (strips + 2) + kMedStripLanes - 1) / kMedStripLanes), 1, (unsigned)fb.nframes);
+        hipLaunchKernelGGL(k_median5x5_strip, grid, dim3(64), 0, s, in, out, (int)rowbytes, h, bandrows, pairs, fb.stride);
         return hipGetLastError();
     }
     const dim3 grid((w + kMedTW - 1) / kMedTW, (h + kMedTR - 1) / kMedTR, (unsigned)fb.nframes);
