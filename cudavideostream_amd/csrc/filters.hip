@@ -1246,6 +1246,11 @@ void k_median5x5_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, int
     const bool stores = inside && lane >= 1u && lane <= (uint32_t)kMedStripLanes;
     const uint32_t outA = stores ? colA : kOut, outB = stores ? colB : kOut;
 
+    // The halves of a register are the bytes themselves, 0x0000 .. 0x00ff: as half floats, zero and the first 255 DENORMALS,
+    // whose order is the bytes' order.  Minimum and maximum return them unchanged as long as half-float denormals are not
+    // flushed -- the compiler's default for this target (.amdhsa_float_denorm_mode_16_64 3), set here regardless: MODE bits
+    // 4..7 = keep denormals as inputs and results, single and half / double (the kernel has no other arithmetic).
+    __builtin_amdgcn_s_setreg((4 - 1) << 11 | 4 << 6 | 1 /* hwreg(HW_REG_MODE, 4, 4) */, 0xf);
     struct Raw { med_u32x2 a, b; };
     auto load_row = [&](int i) {   // row ya - 2 + i of band A, the same row of band B
         Raw v;
@@ -1258,7 +1263,7 @@ void k_median5x5_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, int
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const uint32_t sel = 0x0c000c00u | (uint32_t)(q & 3) | ((uint32_t)(4 + (q & 3)) << 16);
-            p[q] = med_from(__builtin_amdgcn_perm(q < 4 ? v.b.x : v.b.y, q < 4 ? v.a.x : v.a.y, sel) | 0x04000400u);
+            p[q] = med_from(__builtin_amdgcn_perm(q < 4 ? v.b.x : v.b.y, q < 4 ? v.a.x : v.a.y, sel));
         }
     };
 
