@@ -330,6 +330,17 @@ def parity_of_secondary_lines(args, dev, frames):
         for t in range(T):
             ok4 = ok4 and np.array_equal(vis[t].cpu().numpy(), po.red_overlap(np.zeros(n, np.uint8), exs[eo[t]:eo[t + 1]]))
         res["config4"] = bool(ok4)
+    # the 5x5 median (not on the server's path; its line stands beside the filter chains): a 640 x 360 crop of the same
+    # stream through the same column-strip kernel (the oracle sorts 25 bytes per output: 10 s for a 1080p frame)
+    cw, ch = 640, 360
+    if W >= cw and H >= ch:
+        crop = np.ascontiguousarray(h[1].reshape(H, W, 3)[:ch, :cw]).reshape(-1)
+        with CUDACore(cw, ch) as c:
+            c.use_torch_stream()
+            d_o = torch.empty(crop.size, dtype=torch.uint8, device=dev)
+            c.median5x5(torch.from_numpy(crop).to(dev), d_o)
+            torch.cuda.synchronize()
+            res["median5x5"] = bool(np.array_equal(d_o.cpu().numpy(), po.median5x5(crop, cw, ch)))
     return res
 
 
@@ -1044,6 +1055,14 @@ def filter_configs(args, dev, B=192, reps=10):
                          "achieved_gbps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4),
                          "basis": "wall clock per frame on the core's own stream (filters of a batch beside the expansion of "
                                   "the batch before); sequential_us_per_frame: the same calls on a caller's stream"}
+        # the 5x5 median the reference evaluated and left out of its server (tests/noise_filter_benchmark/v3.cu): the one
+        # kernel here that is bound by arithmetic (packed 16-bit min / max), not by HBM; N read + N written
+        core.use_torch_stream()
+        us = wall_us(lambda: core.filter_batch(L.OP_MEDIAN5X5, cur, vis, B))
+        res["median5x5"] = {"workload": "5x5 median per colour channel, zeros outside the image; not on the server's path",
+                            "us_per_frame": round(us, 3), "frames_per_launch": B, "algorithmic_bytes_per_frame": 2 * n,
+                            "achieved_gbps": round(2 * n / (us * 1e-6) / 1e9, 1), "frac": round(2 * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "bound": "valu: ~43 packed min / max class instructions per output byte (DESIGN.md K6), HBM idle"}
     return res
 
 

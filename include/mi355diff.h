@@ -112,9 +112,9 @@ int mi355_synchronize(mi355_core *core);
 #define MI355_OPT_CHAIN_HINT 4   /* 1 (default): a batch that follows a frame filter on this core is not overlapped; 0: is */
 #define MI355_OPT_PACK_BLOCKS 5  /* -1 (default): the pipelined pack kernel runs on 4 workgroups per CU; 0: one tile per
                                   * wave; n > 0: n workgroups */
-#define MI355_OPT_MEDIAN_ROWS 6  /* 0 (default): the 5x5 median's column-strip kernel walks bands of 10..40 rows, chosen from
-                                  * the batch size (long bands read fewer rows twice, short ones make more waves);
-                                  * 5, 10, .. 60: this many */
+#define MI355_OPT_MEDIAN_ROWS 6  /* 0 (default): the 5x5 median's column-strip kernel walks bands of 5..60 rows, chosen per launch
+                                  * (the length that wastes least of the frame's last pair of bands among those that make a few
+                                  * thousand waves); 5, 10, .. 60: this many */
 int mi355_set_option(mi355_core *core, int option, int value);
 int mi355_get_option(mi355_core *core, int option, int *value);
 
