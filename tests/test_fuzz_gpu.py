@@ -75,6 +75,8 @@ def test_random_filters(po, seed):
     w, h = int(rng.integers(1, 200)), int(rng.integers(1, 40))
     if seed % 4 == 0:
         w = 16 * int(rng.integers(1, 24))                                   # 16-byte rows: the vector paths
+    elif seed % 4 == 2:
+        w, h = 8 * int(rng.integers(1, 48)), int(rng.integers(1, 90))       # 8-byte rows: the median's column strips, several bands
     n = 3 * w * h
     cur = rng.integers(0, 256, n, dtype=np.uint8)
     prev = np.where(rng.random(n) < 0.7, cur, rng.integers(0, 256, n)).astype(np.uint8)
