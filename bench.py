@@ -135,6 +135,8 @@ def board_fingerprint(core, when):
     try:
         out["shader_mhz_under_valu_load"] = round(core.probe_clock(100), 0)
         out["hbm_stream_read_gbps"] = round(core.probe_hbm_read(2048), 0)
+        out["hbm_stream_write_gbps"] = round(core.probe_hbm_write(2048), 0)
+        out["hbm_narrow_write_gbps"] = round(core.probe_hbm_write(2048, narrow=True), 0)   # index + value per lane: the dense expansion's stores
     except Exception as e:   # noqa: BLE001
         out["skipped"] = repr(e)[:120]
     return out

@@ -339,6 +339,13 @@ class CUDACore:
         _l.check(self._lib.mi355_probe_hbm_read(self._h, int(megabytes), C.byref(v)))
         return v.value
 
+    def probe_hbm_write(self, megabytes=2048, narrow=False):
+        """GB/s of plain streaming writes on this board: 16 bytes per lane, or (narrow) the dense expansion's
+        4-byte index + 1-byte value per lane (csrc/diag.hip)."""
+        v = C.c_double(0)
+        _l.check(self._lib.mi355_probe_hbm_write(self._h, int(megabytes), 1 if narrow else 0, C.byref(v)))
+        return v.value
+
     def get_timing(self):
         """(ms in the diff/threshold/pack kernel, ms in pack+scan+gather, launches) since reset."""
         a, b, n = C.c_double(0), C.c_double(0), C.c_int(0)

@@ -56,11 +56,39 @@ __global__ __launch_bounds__(256) void k_hbm_read_probe(const u32x4 *buf, size_t
     if (acc == 0x12345679u) sink[0] = acc;
 }
 
+// Streaming writes: WIDE = 16 bytes per lane and instruction (whole lines, like the filters' outputs); NARROW = what the
+// dense expansion emits per entry: a 4-byte index and a 1-byte value to two arrays, a lane per entry (256 + 64
+// contiguous bytes per wave instruction), non-temporal like the expander's.  Boards whose plain read is the same differ
+// by a quarter here (the S0 regime follows it).
+template <bool NARROW>
+__global__ __launch_bounds__(256) void k_hbm_write_probe(u32x4 *buf, size_t nvec, uint32_t seed) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (NARROW) {
+        // entries: nvec * 16 / 5; indices in the first 4/5 of the buffer, values behind them
+        const size_t entries = nvec * 16 / 5 / 4 * 4;
+        uint32_t *xs = reinterpret_cast<uint32_t *>(buf);
+        uint8_t *df = reinterpret_cast<uint8_t *>(buf) + entries * 4;
+        for (size_t i = i0; i < entries; i += stride) {
+            __builtin_nontemporal_store((uint32_t)i ^ seed, xs + i);
+            __builtin_nontemporal_store((uint8_t)(i + seed), df + i);
+        }
+    } else {
+        for (size_t i = i0; i < nvec; i += stride) {
+            const u32x4 v = {(uint32_t)i, seed, (uint32_t)i ^ seed, 0x5a5a5a5au};
+            __builtin_nontemporal_store(v, buf + i);
+        }
+    }
+}
+
 }  // namespace mi355
 
 using namespace mi355;
 
-extern "C" int mi355_probe_hbm_read(mi355_core *c, size_t megabytes, double *gbps) {
+// One probe: a temporary buffer on the core's device, the kernel four times on the core's stream, the best of the last
+// three passes.  `launch(buffer, bytes, stream)` starts the kernel; returns GB/s of `bytes_counted`.
+template <typename Launch>
+static int run_hbm_probe(mi355_core *c, size_t megabytes, double *gbps, const char *what, Launch launch) {
     if (!c || !gbps) return set_error(MI355_ERR_INVALID, "null argument");
     if (megabytes < 64 || megabytes > 16384) return set_error(MI355_ERR_INVALID, "megabytes outside [64, 16384]");
     // the probe's buffers must live on the core's device, whatever device the calling thread used last (a process that
@@ -83,7 +111,7 @@ extern "C" int mi355_probe_hbm_read(mi355_core *c, size_t megabytes, double *gbp
     for (int rep = 0; rep < 4 && e == hipSuccess; rep++) {   // the first pass warms up; the best of the rest counts
         e = hipEventRecord(e0, s);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_hbm_read_probe, dim3(prop.multiProcessorCount * 8), dim3(256), 0, s, d, bytes / 16, sink);
+            launch(d, bytes, sink, (unsigned)prop.multiProcessorCount * 8u, s);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipEventRecord(e1, s);
@@ -96,9 +124,23 @@ extern "C" int mi355_probe_hbm_read(mi355_core *c, size_t megabytes, double *gbp
     if (e1) (void)hipEventDestroy(e1);
     (void)hipFree(d);
     if (sink) (void)hipFree(sink);
-    if (e != hipSuccess) return set_error(MI355_ERR_HIP, "hbm read probe");
+    if (e != hipSuccess) return set_error(MI355_ERR_HIP, what);
     *gbps = (double)bytes / (best * 1e-3) / 1e9;
     return MI355_OK;
+}
+
+extern "C" int mi355_probe_hbm_read(mi355_core *c, size_t megabytes, double *gbps) {
+    return run_hbm_probe(c, megabytes, gbps, "hbm read probe", [](u32x4 *d, size_t bytes, uint32_t *sink, unsigned blocks, hipStream_t s) {
+        hipLaunchKernelGGL(k_hbm_read_probe, dim3(blocks), dim3(256), 0, s, d, bytes / 16, sink);
+    });
+}
+
+extern "C" int mi355_probe_hbm_write(mi355_core *c, size_t megabytes, int narrow, double *gbps) {
+    if (narrow != 0 && narrow != 1) return set_error(MI355_ERR_INVALID, "narrow: 0 or 1");
+    return run_hbm_probe(c, megabytes, gbps, "hbm write probe", [narrow](u32x4 *d, size_t bytes, uint32_t *, unsigned blocks, hipStream_t s) {
+        if (narrow) hipLaunchKernelGGL((k_hbm_write_probe<true>), dim3(blocks), dim3(256), 0, s, d, bytes / 16, 7u);
+        else hipLaunchKernelGGL((k_hbm_write_probe<false>), dim3(blocks), dim3(256), 0, s, d, bytes / 16, 7u);
+    });
 }
 
 extern "C" int mi355_probe_clock(mi355_core *c, int milliseconds, double *shader_mhz) {

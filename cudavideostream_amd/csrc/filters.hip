@@ -1348,18 +1348,23 @@ void k_median5x5_strip(const uint8_t *in, uint8_t *out, int rowbytes, int h, int
 }
 
 // rows per band of the strip kernel: whole groups of five.  A wave walks a PAIR of bands, so the rows walked per strip are
-// pairs x rows >= h / 2: the band length that wastes least of the last pair wins (1080 rows: 45 or 60, twelve or nine
-// full pairs; 40 would walk 14 x 40 = 560 rows for 540), as long as the launch still has a few thousand waves; among
-// equals the longer band (a band reads four rows more than it writes).  One frame: 5 rows, 1260 waves at 1080p.
+// pairs x rows >= h / 2: the band length that wastes least of the last pair wins (1080 rows: 20, 30, 45 or 60 -- 27, 18, 12
+// or 9 full pairs; 40 would walk 14 x 40 = 560 rows for 540), and among equals the SHORTEST from 20 rows up: they measure
+// the same (a band reads four rows more than it writes, but HBM is idle; profiles/r05y_median_rows.txt) and more, shorter
+// waves leave a shorter tail in the chip's last round.  Fewer than 4096 waves: shorter bands still (one frame: 5 rows, 1260
+// waves at 1080p).
 static int median_bandrows(int h, int strips, int nframes) {
-    int best = 5;
-    long best_rows = -1;
-    for (int rows = 5; rows <= 60; rows += 5) {
+    auto waves = [&](int rows) {
         const long pairs = (h + 2 * rows - 1) / (2 * rows);
-        const long waves = (pairs * (strips + 2) + kMedStripLanes - 1) / kMedStripLanes * nframes;
-        if (rows > 5 && waves < 4096) break;
-        if (best_rows < 0 || pairs * rows <= best_rows) { best = rows; best_rows = pairs * rows; }
+        return (pairs * (strips + 2) + kMedStripLanes - 1) / kMedStripLanes * nframes;
+    };
+    int best = 20;
+    long best_rows = -1;
+    for (int rows = 20; rows <= 60; rows += 5) {
+        const long walked = (long)((h + 2 * rows - 1) / (2 * rows)) * rows;
+        if (best_rows < 0 || walked < best_rows) { best = rows; best_rows = walked; }
     }
+    while (best > 5 && waves(best) < 4096) best -= 5;
     return best;
 }
 

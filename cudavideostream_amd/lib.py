@@ -100,6 +100,7 @@ SYMBOLS = {
     "mi355_reset_timing": (C.c_int, [C.c_void_p]),
     "mi355_probe_clock": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "mi355_probe_hbm_read": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_double)]),
+    "mi355_probe_hbm_write": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     # multi-GPU (csrc/group.hip)
     "mi355_group_create": (C.c_int, [C.POINTER(Config), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
     "mi355_group_unique_id": (C.c_int, [C.c_void_p]),

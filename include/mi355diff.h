@@ -62,7 +62,8 @@ typedef struct mi355_config {
  *   4  round 4: + mi355_abi_version, mi355_probe_clock, mi355_probe_hbm_read (additions only)
  *   5  round 5: + mi355_set_option / mi355_get_option; MI355_FLAG_FUSED / MI355_FLAG_CHAIN (two opt-in experiments) are
  *      gone and cfg.flags must be 0; the environment variables MI355_SPLIT, MI355_DENSE_PCT, MI355_CHAIN_HINT and the
- *      undocumented tuning variables are no longer read (options below) */
+ *      undocumented tuning variables are no longer read (options below); + MI355_OPT_MEDIAN_ROWS, mi355_probe_hbm_write
+ *      (additions) */
 #define MI355_ABI_VERSION 5
 int mi355_abi_version(void);
 
@@ -113,8 +114,8 @@ int mi355_synchronize(mi355_core *core);
 #define MI355_OPT_PACK_BLOCKS 5  /* -1 (default): the pipelined pack kernel runs on 4 workgroups per CU; 0: one tile per
                                   * wave; n > 0: n workgroups */
 #define MI355_OPT_MEDIAN_ROWS 6  /* 0 (default): the 5x5 median's column-strip kernel walks bands of 5..60 rows, chosen per launch
-                                  * (the length that wastes least of the frame's last pair of bands among those that make a few
-                                  * thousand waves); 5, 10, .. 60: this many */
+                                  * (from 20 rows up the length that wastes least of the frame's last pair of bands; shorter
+                                  * when that makes fewer than a few thousand waves); 5, 10, .. 60: this many */
 int mi355_set_option(mi355_core *core, int option, int value);
 int mi355_get_option(mi355_core *core, int option, int *value);
 
@@ -380,6 +381,10 @@ int mi355_probe_clock(mi355_core *core, int milliseconds, double *shader_mhz);
 /* Diagnostics: GB/s of a plain streaming read of a temporary `megabytes` MB buffer (64..16384; best of three passes):
  * what this board's memory system gives a read-only kernel.  The pack kernel is bound by it; boards differ by ~7 %. */
 int mi355_probe_hbm_read(mi355_core *core, size_t megabytes, double *gbps);
+/* Diagnostics: GB/s of plain streaming WRITES into a temporary buffer (non-temporal, best of three passes): narrow = 0:
+ * 16 bytes per lane (whole lines, the filters' outputs); narrow = 1: what a dense expansion emits, a 4-byte index and a
+ * 1-byte value per lane to two arrays.  Boards with the same read rate differ by a quarter in this one. */
+int mi355_probe_hbm_write(mi355_core *core, size_t megabytes, int narrow, double *gbps);
 
 #ifdef __cplusplus
 }

@@ -20,8 +20,10 @@ B = 96
 
 
 def find(sub, pat):
+    # gpurun merges every call's output into gpurun_out/: a directory may hold the files of earlier calls (other process
+    # numbers) beside this one's -- the newest is this call's
     r = glob.glob(os.path.join(src, sub, "**", pat), recursive=True)
-    return r[0] if r else None
+    return max(r, key=os.path.getmtime) if r else None
 
 
 def rows(path):
