@@ -25,4 +25,20 @@ for k, d in acc.items():
     print(k)
     for c, v in sorted(d.items()):
         print(f"   {c:28s} n={len(v)} avg={sum(v)/len(v):.4g}")
+# The clock a kernel ran at: GRBM_GUI_ACTIVE (cycles, summed over the 8 XCDs) / 8 / the launch's duration in the same pass's
+# kernel trace.  Only for launches of 100 us and more (the counter's window is wider than a short kernel).
+import os
+cc = sorted(glob.glob(out + "/g3/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+kt = sorted(glob.glob(out + "/g3/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
+if cc and kt:
+    dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kt[-1]))}
+    ghz = collections.defaultdict(list)
+    for r in csv.DictReader(open(cc[-1])):
+        d = dur.get(r["Dispatch_Id"], 0)
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and "mi355" in r["Kernel_Name"] and d >= 100000:
+            ghz[r["Kernel_Name"].split("(")[0][-40:]].append(float(r["Counter_Value"]) / 8.0 / d)
+    print("shader clock during the kernel (GHz): GRBM_GUI_ACTIVE / 8 XCDs / duration, launches >= 100 us")
+    for k, v in ghz.items():
+        v.sort()
+        print(f"   {k:42s} n={len(v)} min={v[0]:.3f} median={v[len(v)//2]:.3f} max={v[-1]:.3f}")
 PY
