@@ -90,7 +90,8 @@ __global__ __launch_bounds__(64) void k_corun_mem(const uint4 *buf, size_t nvec,
 int main(int argc, char **argv) {
     int W = 1920, H = 1080, B = 256, K = 20, WU = 3, checksum_t = -2, ncores = 1;
     uint32_t seed = 21;
-    bool pairs = false, filters = false, digest = false, apart = false;
+    bool pairs = false, filters = false, digest = false, apart = false, print_ptrs = false;
+    size_t skew_xs = 0, skew_df = 0;
     const char *corun = nullptr; int corun_blocks = 2048;
     std::vector<std::pair<int, int>> opts;
     const char *regime = nullptr;   // --regime s0|flip|static: pairs of the dense / static regimes (tools/bench_regimes.py's inputs)
@@ -111,6 +112,9 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--corun") && i + 1 < argc) corun = argv[++i];
         else if (!strcmp(argv[i], "--regime") && i + 1 < argc) { regime = argv[++i]; pairs = true; }
         else if (!strcmp(argv[i], "--corun-blocks")) next(corun_blocks);
+        else if (!strcmp(argv[i], "--skew-xs") && i + 1 < argc) skew_xs = (size_t)atoll(argv[++i]) & ~(size_t)15;
+        else if (!strcmp(argv[i], "--skew-df") && i + 1 < argc) skew_df = (size_t)atoll(argv[++i]) & ~(size_t)15;
+        else if (!strcmp(argv[i], "--print-ptrs")) print_ptrs = true;
         else if (!strcmp(argv[i], "--opt") && i + 1 < argc) { int id = 0, v = 0; if (sscanf(argv[++i], "%d=%d", &id, &v) == 2) opts.push_back({id, v}); }
     }
     auto apply_opts = [&](mi355_core *c) { for (auto &o : opts) MI_OK(mi355_set_option(c, o.first, o.second)); };
@@ -253,8 +257,13 @@ int main(int argc, char **argv) {
     const size_t cap = regime ? (size_t)B * n : ((size_t)B * n / 8 > (1u << 20) ? (size_t)B * n / 8 : (1u << 20));
     uint32_t *d_off; int32_t *d_xs; uint8_t *d_df;
     HIP_OK(hipMalloc((void **)&d_off, sizeof(uint32_t) * (B + 1)));
-    HIP_OK(hipMalloc((void **)&d_xs, sizeof(int32_t) * cap));
-    HIP_OK(hipMalloc((void **)&d_df, cap));
+    // --skew-xs / --skew-df BYTES (multiples of 16): the output arrays displaced inside a larger allocation -- does the
+    // expansion's time depend on WHERE its outputs lie (profiles/r05ae_*)?  --print-ptrs shows the addresses.
+    HIP_OK(hipMalloc((void **)&d_xs, sizeof(int32_t) * cap + skew_xs));
+    HIP_OK(hipMalloc((void **)&d_df, cap + skew_df));
+    d_xs = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(d_xs) + skew_xs);
+    d_df += skew_df;
+    if (print_ptrs) fprintf(stderr, "d_xs %p d_df %p d_off %p frames %p\n", (void *)d_xs, (void *)d_df, (void *)d_off, (void *)(pairs ? d_cur : d_frames));
 
     auto step = [&]() {
         if (pairs) MI_OK(mi355_diff_pairs_batch(core, d_cur, d_prev, apart ? 2 * n : n, B, d_off, d_xs, d_df, cap));
