@@ -91,7 +91,7 @@ int main(int argc, char **argv) {
     int W = 1920, H = 1080, B = 256, K = 20, WU = 3, checksum_t = -2, ncores = 1;
     uint32_t seed = 21;
     bool pairs = false, filters = false, digest = false, apart = false, print_ptrs = false;
-    size_t skew_xs = 0, skew_df = 0;
+    size_t skew_xs = 0, skew_df = 0, skew_frames = 0;
     const char *corun = nullptr; int corun_blocks = 2048;
     std::vector<std::pair<int, int>> opts;
     const char *regime = nullptr;   // --regime s0|flip|static: pairs of the dense / static regimes (tools/bench_regimes.py's inputs)
@@ -114,6 +114,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--corun-blocks")) next(corun_blocks);
         else if (!strcmp(argv[i], "--skew-xs") && i + 1 < argc) skew_xs = (size_t)atoll(argv[++i]) & ~(size_t)15;
         else if (!strcmp(argv[i], "--skew-df") && i + 1 < argc) skew_df = (size_t)atoll(argv[++i]) & ~(size_t)15;
+        else if (!strcmp(argv[i], "--skew-frames") && i + 1 < argc) skew_frames = (size_t)atoll(argv[++i]) & ~(size_t)15;
         else if (!strcmp(argv[i], "--print-ptrs")) print_ptrs = true;
         else if (!strcmp(argv[i], "--opt") && i + 1 < argc) { int id = 0, v = 0; if (sscanf(argv[++i], "%d=%d", &id, &v) == 2) opts.push_back({id, v}); }
     }
@@ -230,7 +231,8 @@ int main(int argc, char **argv) {
 
     uint8_t *d_frames = nullptr, *d_base = nullptr;
     const int nfr = apart ? 2 * B : B + 1;
-    HIP_OK(hipMalloc((void **)&d_frames, n * (size_t)nfr));
+    HIP_OK(hipMalloc((void **)&d_frames, n * (size_t)nfr + skew_frames));
+    d_frames += skew_frames;
     HIP_OK(hipMalloc((void **)&d_base, n));
     const dim3 g((unsigned)((n + 255) / 256)), b(256);
     hipLaunchKernelGGL(k_webcam_frame, g, b, 0, 0, d_base, -1, W, H, seed);
