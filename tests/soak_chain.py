@@ -54,6 +54,8 @@ def run(rounds, seed, w=320, h=180, T=5, verbose=True):
         torch.cuda.synchronize()
         for i in range(nops):
             op = int(rng.integers(0, 7))
+            if int(rng.integers(0, 24)) == 0:
+                op = 7       # (rarely: the oracle sorts 25 bytes per output byte)
             f0 = int(rng.integers(0, 64 - 2 * T))
             o = outs[i]
             if op == 0:      # stream batch straight from the pool
@@ -66,6 +68,12 @@ def run(rounds, seed, w=320, h=180, T=5, verbose=True):
                 filt = np.stack([po.conv3x3(f, w, h, k9) for f in pool[f0:f0 + T]])
                 eo, exs, edf, state = po.diff_stream(filt, state)
                 checks.append(("conv+stream", o, (eo, exs, edf)))
+            elif op == 7:    # 5x5 median (column-strip kernel: 960-byte rows) into the scratch, stream batch out of it
+                core.filter_batch(lib.OP_MEDIAN5X5, d_pool[f0:f0 + T], scratch, T)
+                core.diff_stream_batch(scratch, T, *o, T * n)
+                filt = np.stack([po.median5x5(f, w, h) for f in pool[f0:f0 + T]])
+                eo, exs, edf, state = po.diff_stream(filt, state)
+                checks.append(("median+stream", o, (eo, exs, edf)))
             elif op == 2:    # pairs of consecutive frames
                 core.diff_pairs_batch(d_pool[f0 + 1:f0 + T + 1], d_pool[f0:f0 + T], T, *o, T * n)
                 checks.append(("pairs", o, oracle_pairs(pool[f0 + 1:f0 + T + 1], pool[f0:f0 + T])))
@@ -73,7 +81,7 @@ def run(rounds, seed, w=320, h=180, T=5, verbose=True):
                 blk, hb = d_pool[f0:f0 + 2 * T], pool[f0:f0 + 2 * T]
                 core.diff_pairs_batch(blk[1::2], blk[0::2], T, *o, T * n, stride=2 * n)
                 checks.append(("pairs apart", o, oracle_pairs(hb[1::2], hb[0::2])))
-            elif op == 4 and checks and checks[-1][0] in ("stream", "conv+stream"):   # red map of the batch before
+            elif op == 4 and checks and checks[-1][0] in ("stream", "conv+stream", "median+stream"):   # red map of the batch before
                 prev_o = checks[-1][1]
                 core.red_stream_batch(prev_o[0], prev_o[1], T, vis, True)
                 eo, exs, _ = checks[-1][2]
