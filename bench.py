@@ -17,8 +17,10 @@ N GPUs : one process per GPU (torch.distributed, backend nccl = RCCL); every ran
          `python bench.py --gpus N` starts the N ranks itself when no launcher has (WORLD_SIZE unset); under
          `python -m torch.distributed.run ... bench.py --gpus N` this process is one of them.  With a group the line also
          carries ranks_seen, gather_ms / gather_bytes, gather_verified and `gather_every` (the same job with a gather
-         after EVERY batch).  If the RCCL group below the C-ABI cannot be formed the run FAILS (exit 3) unless
-         --allow-gather-fallback is given.
+         after EVERY batch).  If the RCCL group below the C-ABI cannot be formed, a run whose exchange lies INSIDE the
+         timed steps (--gather last / every) FAILS (exit 3) unless --allow-gather-fallback is given; with the default
+         (--gather after: the exchange behind the timed steps) the steps are measured all the same, the exchange runs in
+         its torch.distributed form, and config.gather_impl says so with the library's error.
 config 5 (BASELINE.json configs[4], 4K frames dealt round-robin over the GPUs, RCCL gather over xGMI):
          python bench.py --gpus 8 --shard roundrobin --width 3840 --height 2160 --batch 64
 
@@ -532,7 +534,10 @@ def main():
             gather_impl = "torch.distributed (mi355_group unavailable on another rank)"
         if group is None:
             core.use_torch_stream()   # the torch.distributed form of the exchange runs on torch's stream
-        if group is None and (not args.allow_gather_fallback or rehearse):
+        # ... except where the exchange is not inside the timed steps at all (--gather after, the default): the steps'
+        # value stands by itself, and the line names the form of the exchange that ran behind them (gather_impl)
+        fallback_ok = args.allow_gather_fallback or args.gather == "after"
+        if group is None and (not fallback_ok or rehearse):
             # a scaling line must measure the path's own exchange: no silent change of what is timed
             print(f"bench.py: rank {rank}: the RCCL group could not be formed ({gather_impl}); "
                   f"--allow-gather-fallback measures the torch.distributed form instead", file=sys.stderr, flush=True)

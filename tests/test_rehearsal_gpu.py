@@ -78,3 +78,31 @@ def test_one_rank_under_the_launcher_reports_the_gather():
     assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["gather_verified"] is True
     assert line["gather_ms"] is not None and line["gather_bytes"] > 0
     assert "RCCL" in line["config"]["gather_impl"] and "rehearsal" not in line
+
+
+def test_one_rank_whose_group_cannot_be_formed_still_measures_its_steps():
+    """The default job (--gather after: the exchange behind the timed steps) under the launcher with real torch.distributed
+    (backend nccl = RCCL), when the library behind the C-ABI cannot load its RCCL: the steps are measured all the same, the
+    exchange runs in its torch.distributed form over device tensors, and the line says which form with the library's error.
+    The same failure with the exchange INSIDE the timed steps ends the job instead."""
+    import socket
+
+    def launch(extra):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL + extra
+        r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420,
+                           env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MI355_RCCL_LIB="/nonexistent/librccl.so"))
+        lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+        return r, (json.loads(lines[-1]) if lines else None)
+
+    r, line = launch([])
+    err = r.stderr.decode(errors="replace")
+    assert r.returncode == 0 and line is not None, err[-3000:]
+    assert "forming the group failed in mi355_group_unique_id" in err
+    assert line["config"]["gather_impl"].startswith("torch.distributed (mi355_group unavailable")
+    assert line["value"] > 0 and line["ranks_seen"] == 1
+    r, line = launch(["--gather", "last"])
+    assert r.returncode != 0 and line is None
