@@ -65,7 +65,18 @@ def pmc_counters(B, W, H):
         return None
     if (rec.get("batch"), rec.get("width"), rec.get("height")) != (B, W, H):
         return None
-    if not rec.get("lib_sha256") or rec["lib_sha256"] != lib_sha256():
+    # the counters belong to one build of the library: the file's hash, or (the file differs between build directories)
+    # the hash of the sources it was built from (profiles/srchash.py)
+    same_lib = rec.get("lib_sha256") and rec["lib_sha256"] == lib_sha256()
+    same_src = False
+    if not same_lib and rec.get("src_sha256"):
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "profiles"))
+            from srchash import src_sha256
+            same_src = rec["src_sha256"] == src_sha256(ROOT)
+        except Exception:   # noqa: BLE001
+            same_src = False
+    if not (same_lib or same_src):
         return None
     return rec
 

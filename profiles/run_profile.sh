@@ -13,6 +13,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 sha256sum $ROOT/cudavideostream_amd/libmi355diff.so > $OUT/lib.sha256
+python3 $ROOT/profiles/srchash.py > $OUT/src.sha256
 ARGS="bench.py --steps $STEPS --warmup 2 --no-cpu --no-pair --no-host-path --no-filters"
 cd $ROOT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || echo "trace failed"

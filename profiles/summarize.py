@@ -100,12 +100,14 @@ if pmc:
         shafile = os.path.join(src, "lib.sha256")
         if os.path.exists(shafile):
             sha = open(shafile).read().split()[0]
+        srcfile = os.path.join(src, "src.sha256")
+        src_sha = open(srcfile).read().split()[0] if os.path.exists(srcfile) else None
         kernels = {}
         for short, d in per_kernel.items():
             if "fetch_raw_bytes" in d and "write_bytes" in d:
                 kernels[short] = {"name": d["name"], "read_bytes": int(2 * d["fetch_raw_bytes"]),
                                   "fetch_size_raw_bytes": int(d["fetch_raw_bytes"]), "write_bytes": int(d["write_bytes"])}
-        json.dump({"tag": tag, "batch": 256, "width": 1920, "height": 1080, "lib_sha256": sha,
+        json.dump({"tag": tag, "batch": 256, "width": 1920, "height": 1080, "lib_sha256": sha, "src_sha256": src_sha,
                    "kernels": kernels,
                    "hbm_bytes_per_launch": int(sum(k["read_bytes"] + k["write_bytes"] for k in kernels.values())),
                    "note": "per launch of a 256-frame 1080p S1 batch; read_bytes = 2 x FETCH_SIZE (gfx950 tallies a "
