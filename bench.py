@@ -191,6 +191,8 @@ def parse():
     p.add_argument("--allow-gather-fallback", action="store_true",
                    help="N > 1 only: if the RCCL group below the C-ABI cannot be formed, measure the torch.distributed "
                         "form of the exchange instead of failing (the line then says so in config.gather_impl)")
+    p.add_argument("--steady-steps", type=int, default=1000,
+                   help="N = 1: the step repeated this many times behind the timed region (`steady_state`); 0: skip")
     p.add_argument("--gather-every-steps", type=int, default=10,
                    help="N > 1: steps of the secondary `gather_every` measurement (a gather after EVERY batch)")
     p.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -634,6 +636,23 @@ def main():
         tgs = torch.tensor([time.perf_counter() - tg0], dtype=torch.float64, device=cdev)
         dist.all_reduce(tgs, op=dist.ReduceOp.MAX)
         gather_after_s = float(tgs.item())
+    # What the path SUSTAINS (N = 1): the same step `--steady-steps` times (default 1000: half a second), right behind the
+    # timed region.  A chip that has been idle needs ~10 ms of this load to reach its clocks, runs at 0.95-0.99 of the
+    # roofline while it is cool and at 0.86-0.90 once it is warm (profiles/r05ao_*, r05ap_*): the K timed steps of a short
+    # run sit on that ramp, this figure does not.
+    steady = None
+    if world == 1 and args.steady_steps > 0:
+        K3 = args.steady_steps
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(K3):
+            if rr:
+                core.diff_pairs_batch(frames, prevs, B, d_off, d_xs, d_df, cap)
+            else:
+                core.diff_stream_batch(frames, B, d_off, d_xs, d_df, cap)
+        core.synchronize()
+        torch.cuda.synchronize()
+        steady = (K3, time.perf_counter() - ts)
     g_last = dict(gstat)
     # secondary measurement (N > 1): the same job with the gather after EVERY batch -- the exchange at its worst
     # (every byte of every rank funnelled to one GPU), so that the scaling curve shows what the gather costs
@@ -728,6 +747,18 @@ def main():
             "roofline": path_roofline(alg_bytes, (ms_pack, ms_scan, ms_expand), launches, rr, pmc,
                                       wall_ms=elapsed / K * 1e3 if pipelined else None),
         }
+        if steady is not None:
+            k3, s3 = steady
+            out["steady_state"] = {"steps": k3, "seconds": round(s3, 3), "frames_per_s": round(B * k3 / s3, 1),
+                                   "ms_per_step": round(s3 / k3 * 1e3, 4),
+                                   "achieved_gbps": round(alg_bytes / (s3 / k3) / 1e9, 1),
+                                   "frac": round(alg_bytes / (s3 / k3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                   "actual_gbps": (round(pmc["hbm_bytes_per_launch"] / (s3 / k3) / 1e9, 1) if pmc else None),
+                                   "note": "the same step repeated right behind the K timed steps, wall clock between device "
+                                           "synchronisations: what the path sustains once the chip has reached its clocks "
+                                           "(a short timed region sits on the ramp: DESIGN.md section 8).  frac is on the "
+                                           "ALGORITHMIC 2N + 5P like the headline's (the state stays in registers: the chip "
+                                           "moves 0.69 of them, actual_gbps -- so frac can pass 1 on a cool chip)"}
         if world == 1 and not args.no_pair and not rr:
             out["pair_mode"] = pair_mode(args, core, frames, d_off, d_xs, d_df, cap, n)
             out["regimes"] = regimes(args, dev)
