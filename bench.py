@@ -866,12 +866,34 @@ def host_path(args, base, frames, reps=60):
             "pcie_h2d_gbps": round(preps * n / dt_pipe / 1e9, 2)}
 
 
+RAMP_MS = 15.0   # a chip that has been idle needs ~12 ms of load to reach its clocks (profiles/r05ar_*)
+
+
+def warm_up(core, fn, warm):
+    """The SECONDARY lines' warm-up: `warm` calls, then as many more as it takes to have the chip under this load for
+    RAMP_MS (their timed regions are a few milliseconds long: without this they would measure the clock ramp.  The
+    headline's warm-up is the driver's --warmup, not this)."""
+    def sync():
+        core.synchronize()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(max(warm, 1)):
+        fn()
+    sync()
+    for _ in range(2):
+        el = time.perf_counter() - t0
+        if el * 1e3 >= RAMP_MS:
+            break
+        per = el / max(warm, 1)
+        for _ in range(min(int((RAMP_MS * 1e-3 - el) / max(per, 1e-6)) + 1, 5000)):
+            fn()
+        sync()
+
+
 def timed_path(core, fn, reps, warm=3):
     """Runs fn() reps times with the core's kernel timers on: (seconds per call, (pack, scan, expand) ms sums, launches)."""
     core.set_timing(True)
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
+    warm_up(core, fn, warm)
     core.reset_timing()
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -886,10 +908,7 @@ def timed_path(core, fn, reps, warm=3):
 def wall_per_call(core, fn, reps, warm=3):
     """Seconds per fn() on the core's OWN stream (consecutive batches pipelined inside the library, as the headline
     runs), wall clock between device synchronisations."""
-    for _ in range(warm):
-        fn()
-    core.synchronize()
-    torch.cuda.synchronize()
+    warm_up(core, fn, warm)
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()
@@ -955,9 +974,8 @@ def two_streams(args, core, frames, base, d_off, d_xs, d_df, cap, dev, reps=20):
                 core.diff_stream_batch(frames, B, d_off, d_xs, d_df, cap)
                 core2.diff_stream_batch(frames2, B, *o2, cap)
 
-            for _ in range(3):
-                both()
-            torch.cuda.synchronize()
+            warm_up(core, both, 3)
+            core2.synchronize()
             t0 = time.perf_counter()
             for _ in range(reps):
                 both()
@@ -1074,10 +1092,7 @@ def filter_configs(args, dev, B=192, reps=10):
             core.red_stream_batch(d_off, d_xs, B, vis)
 
         def wall_us(fn):
-            for _ in range(3):
-                fn()
-            core.synchronize()
-            torch.cuda.synchronize()
+            warm_up(core, fn, 3)
             t0 = time.perf_counter()
             for _ in range(reps):
                 fn()
