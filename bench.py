@@ -192,7 +192,8 @@ def parse():
                    help="N > 1 only: if the RCCL group below the C-ABI cannot be formed, measure the torch.distributed "
                         "form of the exchange instead of failing (the line then says so in config.gather_impl)")
     p.add_argument("--steady-steps", type=int, default=1000,
-                   help="N = 1: the step repeated this many times behind the timed region (`steady_state`); 0: skip")
+                   help="the step repeated this many times behind the timed region, no exchange (`steady_state`; N > 1: every "
+                        "rank, MAX over the ranks, frames_per_s of the whole job); 0: skip")
     p.add_argument("--gather-every-steps", type=int, default=10,
                    help="N > 1: steps of the secondary `gather_every` measurement (a gather after EVERY batch)")
     p.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -636,13 +637,15 @@ def main():
         tgs = torch.tensor([time.perf_counter() - tg0], dtype=torch.float64, device=cdev)
         dist.all_reduce(tgs, op=dist.ReduceOp.MAX)
         gather_after_s = float(tgs.item())
-    # What the path SUSTAINS (N = 1): the same step `--steady-steps` times (default 1000: half a second), right behind the
+    # What the path SUSTAINS: the same step `--steady-steps` times (default 1000: half a second), right behind the
     # timed region.  A chip that has been idle needs ~10 ms of this load to reach its clocks, runs at 0.95-0.99 of the
     # roofline while it is cool and at 0.86-0.90 once it is warm (profiles/r05ao_*, r05ap_*): the K timed steps of a short
     # run sit on that ramp, this figure does not.
     steady = None
-    if world == 1 and args.steady_steps > 0:
+    if args.steady_steps > 0:    # (every rank: the same steps between the same barriers, MAX over the ranks, no exchange)
         K3 = args.steady_steps
+        if dist:
+            dist.barrier()
         torch.cuda.synchronize()
         ts = time.perf_counter()
         for _ in range(K3):
@@ -652,7 +655,14 @@ def main():
                 core.diff_stream_batch(frames, B, d_off, d_xs, d_df, cap)
         core.synchronize()
         torch.cuda.synchronize()
-        steady = (K3, time.perf_counter() - ts)
+        if dist:
+            dist.barrier()
+        s3 = time.perf_counter() - ts
+        if dist:
+            t3 = torch.tensor([s3], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+            s3 = float(t3.item())
+        steady = (K3, s3)
     g_last = dict(gstat)
     # secondary measurement (N > 1): the same job with the gather after EVERY batch -- the exchange at its worst
     # (every byte of every rank funnelled to one GPU), so that the scaling curve shows what the gather costs
@@ -749,9 +759,9 @@ def main():
         }
         if steady is not None:
             k3, s3 = steady
-            out["steady_state"] = {"steps": k3, "seconds": round(s3, 3), "frames_per_s": round(B * k3 / s3, 1),
+            out["steady_state"] = {"steps": k3, "seconds": round(s3, 3), "frames_per_s": round(world * B * k3 / s3, 1),
                                    "ms_per_step": round(s3 / k3 * 1e3, 4),
-                                   "achieved_gbps": round(alg_bytes / (s3 / k3) / 1e9, 1),
+                                   "achieved_gbps": round(alg_bytes / (s3 / k3) / 1e9, 1),   # per GPU (rank 0's bytes)
                                    "frac": round(alg_bytes / (s3 / k3) / 1e9 / HBM_PEAK_GBPS, 4),
                                    "actual_gbps": (round(pmc["hbm_bytes_per_launch"] / (s3 / k3) / 1e9, 1) if pmc else None),
                                    "note": "the same step repeated right behind the K timed steps, wall clock between device "
