@@ -92,6 +92,7 @@ int main(int argc, char **argv) {
     uint32_t seed = 21;
     bool pairs = false, filters = false, digest = false, apart = false, print_ptrs = false;
     size_t skew_xs = 0, skew_df = 0, skew_frames = 0;
+    int reroll = 0;
     const char *corun = nullptr; int corun_blocks = 2048;
     std::vector<std::pair<int, int>> opts;
     const char *regime = nullptr;   // --regime s0|flip|static: pairs of the dense / static regimes (tools/bench_regimes.py's inputs)
@@ -116,6 +117,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--skew-df") && i + 1 < argc) skew_df = (size_t)atoll(argv[++i]) & ~(size_t)15;
         else if (!strcmp(argv[i], "--skew-frames") && i + 1 < argc) skew_frames = (size_t)atoll(argv[++i]) & ~(size_t)15;
         else if (!strcmp(argv[i], "--print-ptrs")) print_ptrs = true;
+        else if (!strcmp(argv[i], "--reroll")) next(reroll);
         else if (!strcmp(argv[i], "--opt") && i + 1 < argc) { int id = 0, v = 0; if (sscanf(argv[++i], "%d=%d", &id, &v) == 2) opts.push_back({id, v}); }
     }
     auto apply_opts = [&](mi355_core *c) { for (auto &o : opts) MI_OK(mi355_set_option(c, o.first, o.second)); };
@@ -322,6 +324,44 @@ int main(int argc, char **argv) {
            pairs ? "pairs" : "stream", W, H, B, K, (double)B * K / sec, sec / K * 1e3, alg / (sec / K) / 8e12, pack_ms, ms_total / (launches ? launches : 1),
            k_pack / (kl ? kl : 1) * 1e3, k_scan / (kl ? kl : 1) * 1e3, k_exp / (kl ? kl : 1) * 1e3,
            p / B, alg / (pack_ms * 1e-3) / 1e9, mhz, hbm, mi355_workspace_bytes(core));
+    if (reroll > 0 && pairs) {
+        // Which buffers' placement decides the dense expansion's speed (profiles/README.md, "two speeds")?  In ONE process:
+        // new output arrays (the old ones stay allocated), then a new core = new logs (created before the old one is
+        // destroyed), then new copies of the input frames; the three kernels' times after every re-draw.
+        auto measure = [&](const char *what, int i) {
+            for (int w = 0; w < WU; w++) MI_OK(mi355_diff_pairs_batch(core, d_cur, d_prev, apart ? 2 * n : n, B, d_off, d_xs, d_df, cap));
+            MI_OK(mi355_synchronize(core));
+            MI_OK(mi355_set_timing(core, 1));
+            MI_OK(mi355_reset_timing(core));
+            for (int k = 0; k < K; k++) MI_OK(mi355_diff_pairs_batch(core, d_cur, d_prev, apart ? 2 * n : n, B, d_off, d_xs, d_df, cap));
+            MI_OK(mi355_synchronize(core));
+            double a = 0, b = 0, c = 0; int l = 0;
+            MI_OK(mi355_get_kernel_timing(core, &a, &b, &c, &l));
+            printf("reroll %s %d: kernels_us [%.1f, %.1f, %.1f]  xs %p df %p\n", what, i, a / l * 1e3, b / l * 1e3, c / l * 1e3, (void *)d_xs, (void *)d_df);
+        };
+        for (int i = 1; i <= reroll; i++) {
+            HIP_OK(hipMalloc((void **)&d_xs, sizeof(int32_t) * cap));
+            HIP_OK(hipMalloc((void **)&d_df, cap));
+            measure("outputs", i);
+        }
+        for (int i = 1; i <= reroll; i++) {
+            mi355_core *fresh = nullptr;
+            MI_OK(mi355_create(&cfg, &fresh));
+            mi355_destroy(core);
+            core = fresh;
+            apply_opts(core);
+            measure("core", i);
+        }
+        for (int i = 1; i <= reroll; i++) {
+            const size_t bytes = (size_t)((regime || apart) ? 2 * B : B + 1) * n;
+            uint8_t *copy = nullptr;
+            HIP_OK(hipMalloc((void **)&copy, bytes));
+            HIP_OK(hipMemcpy(copy, d_prev, bytes, hipMemcpyDeviceToDevice));
+            d_cur = copy + (d_cur - d_prev);
+            d_prev = copy;
+            measure("frames", i);
+        }
+    }
     mi355_destroy(core);
     return 0;
 }
