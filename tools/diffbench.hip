@@ -344,6 +344,14 @@ int main(int argc, char **argv) {
             HIP_OK(hipMalloc((void **)&d_df, cap));
             measure("outputs", i);
         }
+        for (int i = 1; i <= reroll; i++) {   // the index array alone, then the value array alone
+            HIP_OK(hipMalloc((void **)&d_xs, sizeof(int32_t) * cap));
+            measure("xs-only", i);
+        }
+        for (int i = 1; i <= reroll; i++) {
+            HIP_OK(hipMalloc((void **)&d_df, cap));
+            measure("df-only", i);
+        }
         for (int i = 1; i <= reroll; i++) {
             mi355_core *fresh = nullptr;
             MI_OK(mi355_create(&cfg, &fresh));
