@@ -8,7 +8,13 @@
 //   diffbench [--width W] [--height H] [--batch B] [--steps K] [--warmup W] [--seed S]
 //             [--pairs] [--checksum T] [--cores C] [--digest]
 //             [--opt ID=VALUE ...]      mi355_set_option on every core (1 pipeline, 2 split per cent, 3 dense per cent,
-//                                       4 chain hint, 5 pack workgroups: include/mi355diff.h "Options")
+//                                       4 chain hint, 5 pack workgroups, 6 median band rows: include/mi355diff.h "Options")
+//             [--regime s0|flip|static] [--apart]   pairs of the dense / static regimes; pairs that share no frame
+//             [--skew-frames N] [--skew-xs N] [--skew-df N] [--print-ptrs]   the frames / the two output arrays displaced by N
+//                                       bytes inside a larger allocation
+//             [--reroll N]              pairs: after the run, N new pairs of output arrays, N new index arrays, N new value
+//                                       arrays, N new cores, N new copies of the frames -- the kernels' times after each
+//                                       (which buffer's placement decides the dense expansion's speed: profiles/README.md)
 //   diffbench --filters [--batch B] [--steps K]     the filter kernels and the BASELINE config 3 / 4 chains
 //                                                   (same lines as tools/bench_filters.py, for the --pmc passes)
 #include <hip/hip_runtime.h>
