@@ -21,8 +21,18 @@ N GPUs : one process per GPU (torch.distributed, backend nccl = RCCL); every ran
          timed steps (--gather last / every) FAILS (exit 3) unless --allow-gather-fallback is given; with the default
          (--gather after: the exchange behind the timed steps) the steps are measured all the same, the exchange runs in
          its torch.distributed form, and config.gather_impl says so with the library's error.
-config 5 (BASELINE.json configs[4], 4K frames dealt round-robin over the GPUs, RCCL gather over xGMI):
-         python bench.py --gpus 8 --shard roundrobin --width 3840 --height 2160 --batch 64
+config 5 (BASELINE.json configs[4], 4K frames dealt round-robin over the GPUs, RCCL gather over xGMI): whenever a launcher
+         started the job (N > 1; N = 1 under torch.distributed.run) the line carries a `config5` object measured ACROSS the
+         ranks -- a 3840x2160 sequence dealt round-robin over the ranks that are there, 64-frame shards, stateless pairs,
+         then mi355_group_gather to rank 0: frames/s (MAX over the ranks), frac per rank, final_gather_ms, gather_bytes,
+         gather_gbps, ranks_seen, gather_verified, and parity of rank 0's copy of every rank's first and last frame against
+         the oracle.  At N = 1 without a launcher: `config5_per_gpu` (one GPU's share of the same deal over 8 ranks).  The
+         same shape as the WHOLE job: python bench.py --gpus 8 --shard roundrobin --width 3840 --height 2160 --batch 64
+timing : `value` = the W warm-up + K timed steps behind --preheat-s seconds (default 1) of the same step, untimed: a chip that
+         has been idle needs ~12 ms of load to reach its clocks and ~0.3 s to settle; the same W + K steps as the first GPU
+         work of the process are reported beside it (`cold_start_window`: what rounds 1-5 printed), and `steady_state` (1000
+         more steps) behind it.  roofline.frac is on the ALGORITHMIC bytes (2N + 5P); frac_actual / frac_of_achievable on the
+         bytes the chip moved (counters) over 8 TB/s / over this board's plain streaming read.
 
 Prints ONE JSON line on rank 0.  The CPU oracle is used only as the checker / cpu_baseline leg.
 """
@@ -104,7 +114,7 @@ def path_roofline(alg_bytes, ms, launches, pair, pmc=None, wall_ms=None):
                       "frac_of_peak": round(moved / (m * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
         kernels.append(k)
     frac = achieved / HBM_PEAK_GBPS
-    assert 0.0 < frac <= 1.0, f"roofline fraction {frac} outside (0, 1]"
+    assert frac > 0.0, f"roofline fraction {frac}"
     out = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
            "frac": round(frac, 4),
            "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
@@ -116,7 +126,30 @@ def path_roofline(alg_bytes, ms, launches, pair, pmc=None, wall_ms=None):
                                   f"kernels' own durations overlap and add up to {round(sum(per), 4)} ms")
     if pmc:
         out["traffic_source"] = f"profiles/pmc_summary.json ({pmc.get('tag')}, separate --pmc FETCH_SIZE / WRITE_SIZE passes, same library build)"
-        out["actual_gbps"] = round(pmc["hbm_bytes_per_launch"] / (total_ms * 1e-3) / 1e9, 1)
+    out.update(fractions(alg_bytes, pmc["hbm_bytes_per_launch"] if pmc else None, total_ms * 1e-3, pair))
+    return out
+
+
+def fractions(alg_bytes, traffic_bytes, sec_per_launch, pair, stream_gbps=None):
+    """The two truths of a roofline line, side by side.  `frac` (set by the caller) is the contract's: ALGORITHMIC bytes
+    (2N + 5P per frame) / time / 8 TB/s.  It is not HBM utilisation: in stream mode the pack kernel keeps
+    the state in registers across the batch and reads N per frame where the model counts 2N, so the chip moves fewer
+    bytes than the model -- and `frac` can pass 1 on a cool chip without anything being skipped.  `frac_actual` is the
+    bytes the chip really moved (FETCH_SIZE / WRITE_SIZE counters) / time / 8 TB/s, `frac_of_achievable` the same over
+    what a plain streaming read reaches on THIS board (board.hbm_stream_read_gbps, measured in the same run)."""
+    out = {}
+    if traffic_bytes:
+        gbps = traffic_bytes / sec_per_launch / 1e9
+        out["actual_gbps"] = round(gbps, 1)
+        out["frac_actual"] = round(gbps / HBM_PEAK_GBPS, 4)
+        out["traffic_over_algorithmic"] = round(traffic_bytes / alg_bytes, 4)
+        if stream_gbps:
+            out["frac_of_achievable"] = round(gbps / stream_gbps, 4)
+    out["frac_note"] = ("frac = algorithmic 2N + 5P bytes / time / 8 TB/s"
+                        + ("" if pair else "; the stream kernel keeps the state in registers and reads N per frame, not 2N: the chip "
+                           "moves traffic_over_algorithmic of those bytes, so frac is NOT HBM utilisation and can pass 1")
+                        + "; frac_actual = counter bytes / time / 8 TB/s; frac_of_achievable = the same / this board's plain "
+                          "streaming read (board.hbm_stream_read_gbps)")
     return out
 
 
@@ -201,7 +234,16 @@ def parse():
                         "torch.distributed over gloo, the exchange below the C-ABI through the tests' inter-process "
                         "stand-in for RCCL (tests/mock_rccl/librccl_mock_ipc.so; real RCCL refuses two ranks on one "
                         "device) -- to prove the process-per-rank sequence before the first run on an 8-GPU node")
-    p.add_argument("--no-config5", action="store_true", help="skip the config5_per_gpu object (4K round-robin shard on one GPU)")
+    p.add_argument("--no-config5", action="store_true",
+                   help="skip BASELINE configs[4]: the config5_per_gpu object (one GPU's 4K round-robin shard, N = 1) and the "
+                        "config5 object (the 4K sequence dealt over the ranks of this job + the gather, under a launcher)")
+    p.add_argument("--config5-size", type=int, nargs=3, default=[3840, 2160, 64], metavar=("W", "H", "FRAMES"),
+                   help="config5: frame size and frames per rank's shard (the tests take a small one)")
+    p.add_argument("--config5-steps", type=int, default=10, help="config5: timed passes over the shard")
+    p.add_argument("--preheat-s", type=float, default=1.0,
+                   help="seconds of the same step, untimed, in front of the W warm-up + K timed steps (the chip's clock ramp and "
+                        "first heating: DESIGN.md section 8); 0: none -- the W + K steps are then the first GPU work of the process, "
+                        "as in rounds 1-5 (the default run reports that window too: cold_start_window)")
     return p.parse_args()
 
 
@@ -440,6 +482,125 @@ def rehearsal_env():
             "MOCK_RCCL_TIMEOUT_S": os.environ.get("MOCK_RCCL_TIMEOUT_S", "60")}
 
 
+def payload_digest(o, xs, df):
+    """[entries, sum of the offsets, weighted sums of the indices and of the differences] of one rank's packed batch."""
+    pn = int(o[-1].item()) & 0xFFFFFFFF
+    w = torch.arange(pn, device=xs.device, dtype=torch.int64) % 8191 + 1
+    return [pn, int(o.to(torch.int64).sum().item()), int((xs[:pn].to(torch.int64) * w).sum().item()),
+            int((df[:pn].to(torch.int64) * w).sum().item())]
+
+
+class Exchange:
+    """The job's ONE exchange step: gather-v of every rank's (offsets, xs, diff) of a batch to rank 0 -- below the C-ABI
+    (mi355_group_gather: RCCL all-gather of counts + point-to-point sends to the root, csrc/group.hip) when the group
+    could be formed, else its torch.distributed form (cudavideostream_amd/gather.py).  Every method is collective."""
+
+    def __init__(self, group, dist, world, rank, B, cap, dev, cdev):
+        self.group, self.dist, self.world, self.rank, self.B, self.cap, self.dev, self.cdev = group, dist, world, rank, B, cap, dev, cdev
+        self.ms, self.calls, self.bytes, self.ranks_seen = 0.0, 0, 0, world
+        self.root = None   # rank 0: (index[world, B + 1], xs of all ranks in rank order, diff likewise) of the latest gather
+        if group is not None and rank == 0:
+            self.r_off = torch.zeros((world, B + 1), dtype=torch.int32, device=dev)
+            self.r_xs = torch.empty(world * cap, dtype=torch.int32, device=dev)
+            self.r_df = torch.empty(world * cap, dtype=torch.uint8, device=dev)
+
+    def reset(self):
+        self.ms, self.calls, self.bytes = 0.0, 0, 0
+
+    def run(self, d_off, d_xs, d_df):
+        """One gather, timed on its own (a host synchronisation either side: the call has one inside anyway,
+        kernels.cu:507-508)."""
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        if self.group is not None:
+            root = self.rank == 0
+            counts = self.group.gather(0, self.B, [d_off], [d_xs], [d_df], self.cap, self.r_off if root else None,
+                                       self.r_xs if root else None, self.r_df if root else None, self.world * self.cap if root else 0)
+            self.ranks_seen = self.group.nranks
+            total = int(counts.sum())
+            if root:
+                self.root = (self.r_off, self.r_xs, self.r_df)
+        else:
+            totals, xs_all, df_all, index = gx.gather_payload(d_off, d_xs, d_df, dst=0)
+            self.ranks_seen = len(totals)
+            total = int(sum(totals))
+            if self.rank == 0:
+                self.root = (index, xs_all, df_all)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - tg) * 1e3
+        self.ms += ms
+        self.calls += 1
+        self.bytes += 4 * (self.B + 1) * self.world + 5 * total   # what arrives at the root: every rank's index row + 5 bytes per entry, its own part included
+        return ms
+
+    def verify(self, d_off, d_xs, d_df):
+        """Did the root receive what the ranks produced?  To be called right behind run(), before anything rewrites the
+        ranks' arrays, outside every timed region: every rank digests its own (offsets, xs, diff), the digests travel
+        over torch.distributed, rank 0 digests the segment it holds for every rank.  True / False on rank 0, None elsewhere."""
+        torch.cuda.synchronize()
+        mine = torch.tensor(payload_digest(d_off, d_xs, d_df), dtype=torch.int64, device=self.cdev)
+        every = [torch.zeros_like(mine) for _ in range(self.world)]
+        if self.world > 1:
+            self.dist.all_gather(every, mine)
+        else:
+            every = [mine]
+        if self.rank != 0 or self.root is None:
+            return None
+        index, xs_all, df_all = self.root
+        ok, at = True, 0
+        for r in range(self.world):
+            pn = int(every[r][0].item())
+            got = payload_digest(index[r], xs_all[at:], df_all[at:]) if at + pn <= xs_all.numel() else None
+            ok = ok and got == [int(v) for v in every[r].tolist()]
+            at += pn
+        return bool(ok)
+
+
+def form_group(core, dist, world, rank, local_rank, cdev, rehearse):
+    """This process's core joins a group of `world` ranks below the C-ABI (mi355_group_adopt_rank, csrc/group.hip: RCCL)
+    with an id rank 0 makes and torch.distributed hands around.  Returns (group or None, text for config.gather_impl).
+    Every rank takes part in every collective of this function whatever happened to it before: a rank that raised and
+    skipped a broadcast would leave the others waiting in it (torch.distributed's timeout is half an hour); and every
+    rank leaves it the same way (all with a group, or none)."""
+    impl = ("mi355_group_gather (csrc/group.hip) over the tests' inter-process stand-in for RCCL: REHEARSAL"
+            if rehearse else "mi355_group_gather (RCCL, csrc/group.hip)")
+    group = None
+    stage, err = "mi355_group_unique_id", None
+    ident = np.zeros(1 + 128, np.uint8)          # [0] = 1: rank 0 made the id
+    if rank == 0:
+        try:
+            from cudavideostream_amd.group import unique_id
+            ident[1:] = unique_id()
+            ident[0] = 1
+        except Exception as e:   # noqa: BLE001
+            err = e
+    t_id = torch.from_numpy(ident).to(cdev)
+    dist.broadcast(t_id, src=0)
+    ident = t_id.cpu().numpy()
+    if err is None and ident[0] != 1:
+        stage, err = "mi355_group_unique_id on rank 0", RuntimeError("rank 0 could not make the group's id")
+    if err is None:
+        stage = "mi355_group_adopt_rank"
+        try:
+            from cudavideostream_amd.group import CUDAGroup
+            group = CUDAGroup.adopt(core, world, rank, ident[1:])
+        except Exception as e:   # noqa: BLE001
+            group, err = None, e
+    if err is not None:
+        impl = f"torch.distributed (mi355_group unavailable: {repr(err)[:100]})"
+        # WHICH step failed, on WHICH rank, with the library's own text (it names the RCCL entry point:
+        # csrc/group.hip RCCL_TRY) -- before anything else happens to this process
+        print(f"bench.py: rank {rank} of {world} (device {local_rank}): forming the group failed in {stage}: {err!r}",
+              file=sys.stderr, flush=True)
+    ok = torch.tensor([1 if group is not None else 0], device=cdev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank takes the same way
+    if int(ok.item()) == 0 and group is not None:
+        group.close()
+        group = None
+        impl = "torch.distributed (mi355_group unavailable on another rank)"
+    return group, impl
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -505,78 +666,27 @@ def main():
     # (under a launcher the group is formed at N = 1 too: the line then carries ranks_seen / gather_ms / gather_bytes of
     # the same code path the N > 1 runs take)
     if dist is not None and args.gather != "none":
-        gather_impl = ("mi355_group_gather (csrc/group.hip) over the tests' inter-process stand-in for RCCL: REHEARSAL"
-                       if rehearse else "mi355_group_gather (RCCL, csrc/group.hip)")
-        # Every rank takes part in every collective of this block whatever happened to it before: a rank that raised and
-        # skipped a broadcast would leave the others waiting in it (torch.distributed's timeout is half an hour).
-        stage, err = "mi355_group_unique_id", None
-        ident = np.zeros(1 + 128, np.uint8)          # [0] = 1: rank 0 made the id
-        if rank == 0:
-            try:
-                from cudavideostream_amd.group import unique_id
-                ident[1:] = unique_id()
-                ident[0] = 1
-            except Exception as e:   # noqa: BLE001
-                err = e
-        t_id = torch.from_numpy(ident).to(cdev)
-        dist.broadcast(t_id, src=0)
-        ident = t_id.cpu().numpy()
-        if err is None and ident[0] != 1:
-            stage, err = "mi355_group_unique_id on rank 0", RuntimeError("rank 0 could not make the group's id")
-        if err is None:
-            stage = "mi355_group_adopt_rank"
-            try:
-                from cudavideostream_amd.group import CUDAGroup
-                group = CUDAGroup.adopt(core, world, rank, ident[1:])
-                root_cap = world * cap if rank == 0 else 0
-                r_off = torch.zeros((world, B + 1), dtype=torch.int32, device=dev) if rank == 0 else None
-                r_xs = torch.empty(root_cap, dtype=torch.int32, device=dev) if rank == 0 else None
-                r_df = torch.empty(root_cap, dtype=torch.uint8, device=dev) if rank == 0 else None
-            except Exception as e:   # noqa: BLE001
-                group, err = None, e
-        if err is not None:
-            gather_impl = f"torch.distributed (mi355_group unavailable: {repr(err)[:100]})"
-            # WHICH step failed, on WHICH rank, with the library's own text (it names the RCCL entry point:
-            # csrc/group.hip RCCL_TRY) -- before anything else happens to this process
-            print(f"bench.py: rank {rank} of {world} (device {local_rank}): forming the group failed in {stage}: {err!r}",
-                  file=sys.stderr, flush=True)
-        ok = torch.tensor([1 if group is not None else 0], device=cdev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank takes the same way
-        if int(ok.item()) == 0 and group is not None:
-            group.close()
-            group = None
-            gather_impl = "torch.distributed (mi355_group unavailable on another rank)"
-        if group is None:
-            core.use_torch_stream()   # the torch.distributed form of the exchange runs on torch's stream
-        # ... except where the exchange is not inside the timed steps at all (--gather after, the default): the steps'
-        # value stands by itself, and the line names the form of the exchange that ran behind them (gather_impl)
-        fallback_ok = args.allow_gather_fallback or args.gather == "after"
-        if group is None and (not fallback_ok or rehearse):
-            # a scaling line must measure the path's own exchange: no silent change of what is timed
+        group, gather_impl = form_group(core, dist, world, rank, local_rank, cdev, rehearse)
+        # Without the group: where the exchange lies INSIDE the timed steps (--gather last / every / index) a scaling line
+        # must measure the path's own exchange -- no silent change of what is timed: exit 3 unless --allow-gather-fallback
+        # (the torch.distributed form then runs on torch's stream, and so do the batches in front of it).  With the
+        # default (--gather after: the exchange BEHIND the timed steps) the steps run exactly as they do with a group -- on
+        # the core's own stream, pipelined -- and the torch.distributed form of the exchange runs behind them, timed the
+        # same way (final_gather_ms, gather_ran); config.gather_impl names it with the library's error.
+        if group is None and (rehearse or (args.gather != "after" and not args.allow_gather_fallback)):
             print(f"bench.py: rank {rank}: the RCCL group could not be formed ({gather_impl}); "
                   f"--allow-gather-fallback measures the torch.distributed form instead", file=sys.stderr, flush=True)
             dist.barrier()
             dist.destroy_process_group()
             raise SystemExit(3)
+        if group is None and args.gather != "after":
+            core.use_torch_stream()   # the torch.distributed form of the exchange runs on torch's stream, between the batches
 
-    gstat = {"ms": 0.0, "calls": 0, "bytes": 0, "ranks_seen": world if world > 1 else 1}
+    xch = Exchange(group, dist, world, rank, B, cap, dev, cdev) if dist is not None and args.gather != "none" else None
+    gather_verified = None
 
     def exchange_payload():
-        # timed on its own (a host synchronisation either side: the call has one inside anyway, kernels.cu:507-508)
-        torch.cuda.synchronize()
-        tg = time.perf_counter()
-        if group is not None:
-            counts = group.gather(0, B, [d_off], [d_xs], [d_df], cap, r_off, r_xs, r_df, world * cap if rank == 0 else 0)
-            gstat["ranks_seen"] = group.nranks
-            total = int(counts.sum())
-        else:
-            gx.gather_payload(d_off, d_xs, d_df, dst=0)
-            total = -1
-        torch.cuda.synchronize()
-        gstat["ms"] += (time.perf_counter() - tg) * 1e3
-        gstat["calls"] += 1
-        if total >= 0:   # what arrives at the root: every rank's index row + 5 bytes per entry, its own part included
-            gstat["bytes"] += 4 * (B + 1) * world + 5 * total
+        xch.run(d_off, d_xs, d_df)
 
     def step(last):
         if rr:
@@ -594,127 +704,112 @@ def main():
                 core.synchronize()   # d_off is written on the core's side stream; torch.distributed runs on torch's
                 gx.gather_index(d_off, dst=0)
 
+    def plain_step(_last=False):
+        if rr:
+            core.diff_pairs_batch(frames, prevs, B, d_off, d_xs, d_df, cap)
+        else:
+            core.diff_stream_batch(frames, B, d_off, d_xs, d_df, cap)
+
+    def timed_window(k, fn):
+        """EXACTLY k steps bracketed by a barrier + device synchronisation on both sides, MAX over the ranks (seconds)."""
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(k):
+            fn(i == k - 1)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([el], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    # The chip's state.  A chip that has been idle needs ~12 ms of this load to reach its clocks, then runs the path at
+    # 0.95-0.99 of the roofline while it is cool, dips ~0.2 s into the load and settles at its sustained level (0.91-0.92
+    # over 18 s: profiles/r05ao_* ... r05as_*).  W + K steps as the first GPU work of a process (W = 5, K = 20: 12 ms) measure
+    # that ramp, not the path: they are kept as `cold_start_window` (what rounds 1-5 printed as `value`).  The line's
+    # `value` is the same W + K steps behind --preheat-s seconds (default 1) of the same step, untimed: the state a stream
+    # that runs for longer than a second is in.  (`steady_state`, 1000 more steps behind the timed ones, stays as well.)
+    cold = None
+    preheat_steps = 0
+    if args.preheat_s > 0:
+        for _ in range(args.warmup):
+            plain_step()
+        cold = timed_window(K, plain_step)
+        tp = time.perf_counter()
+        while time.perf_counter() - tp < args.preheat_s:
+            for _ in range(64):
+                plain_step()
+            preheat_steps += 64
+            core.synchronize()
+
     for i in range(args.warmup):
         step(i == args.warmup - 1)   # the last warm-up step also runs the exchange (RCCL sets up its peer channels on first use)
-    if group is not None and args.gather == "after":
+    if xch is not None and args.gather == "after":
         exchange_payload()           # ... in every mode
     torch.cuda.synchronize()
     core.set_timing(True)
     core.reset_timing()
-    gstat.update(ms=0.0, calls=0, bytes=0)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(K):
-        step(i == K - 1)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if xch is not None:
+        xch.reset()
+    elapsed = timed_window(K, step)
 
     ms_pack, ms_scan, ms_expand, launches = core.get_kernel_timing()
     core.set_timing(False)
-    pipelined = core.get_option(1) == 1 and (group is not None or dist is None or args.gather == "none")
+    # (the batches ran on the core's own stream, pipelined, unless an exchange in its torch.distributed form lies between them)
+    pipelined = core.get_option(1) == 1 and (group is not None or dist is None or args.gather in ("none", "after"))
+    if xch is not None and args.gather != "after" and xch.calls:
+        gather_verified = xch.verify(d_off, d_xs, d_df)   # the gather inside the last timed step: checked before anything rewrites the arrays
     # The job's ONE exchange ("after"): the final batch's changed-pixel stream of every rank to rank 0, right behind the K
     # timed steps (barrier + device synchronisation either side, MAX over the ranks like the steps' time).  It is the
     # epilogue of a stream, not a step of the hot path: 5 bytes per changed byte of a whole batch over ONE xGMI link per
     # rank (187 MB at 1080p: ~3 ms, against 0.5 ms per step) would be a quarter of a 20-step window and nothing of an
     # hour of video.  `value` is the K steps; `value_with_final_gather` has the exchange in the denominator.
     gather_after_s = None
-    if group is not None and args.gather == "after":
-        dist.barrier()
-        torch.cuda.synchronize()
-        tg0 = time.perf_counter()
-        exchange_payload()
-        torch.cuda.synchronize()
-        dist.barrier()
-        tgs = torch.tensor([time.perf_counter() - tg0], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tgs, op=dist.ReduceOp.MAX)
-        gather_after_s = float(tgs.item())
+    if xch is not None and args.gather == "after":
+        gather_after_s = timed_window(1, lambda _l: exchange_payload())
+        gather_verified = xch.verify(d_off, d_xs, d_df)   # the ranks' digests of THIS batch, before any further step
+    g_last = ({"ms": xch.ms, "calls": xch.calls, "bytes": xch.bytes, "ranks_seen": xch.ranks_seen} if xch is not None
+              else {"ms": 0.0, "calls": 0, "bytes": 0, "ranks_seen": world if world > 1 else 1})
     # What the path SUSTAINS: the same step `--steady-steps` times (default 1000: half a second), right behind the
-    # timed region.  A chip that has been idle needs ~10 ms of this load to reach its clocks, runs at 0.95-0.99 of the
-    # roofline while it is cool and at 0.86-0.90 once it is warm (profiles/r05ao_*, r05ap_*): the K timed steps of a short
-    # run sit on that ramp, this figure does not.
+    # timed region.
     steady = None
     if args.steady_steps > 0:    # (every rank: the same steps between the same barriers, MAX over the ranks, no exchange)
-        K3 = args.steady_steps
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        ts = time.perf_counter()
-        for _ in range(K3):
-            if rr:
-                core.diff_pairs_batch(frames, prevs, B, d_off, d_xs, d_df, cap)
-            else:
-                core.diff_stream_batch(frames, B, d_off, d_xs, d_df, cap)
-        core.synchronize()
-        torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-        s3 = time.perf_counter() - ts
-        if dist:
-            t3 = torch.tensor([s3], dtype=torch.float64, device=cdev)
-            dist.all_reduce(t3, op=dist.ReduceOp.MAX)
-            s3 = float(t3.item())
-        steady = (K3, s3)
-    g_last = dict(gstat)
+        steady = (args.steady_steps, timed_window(args.steady_steps, plain_step))
     # secondary measurement (N > 1): the same job with the gather after EVERY batch -- the exchange at its worst
     # (every byte of every rank funnelled to one GPU), so that the scaling curve shows what the gather costs
     g_every = None
     if world > 1 and group is not None and args.gather_every_steps > 0:
-        gstat.update(ms=0.0, calls=0, bytes=0)
+        xch.reset()
         K2 = args.gather_every_steps
-        dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(K2):
-            if rr:
-                core.diff_pairs_batch(frames, prevs, B, d_off, d_xs, d_df, cap)
-            else:
-                core.diff_stream_batch(frames, B, d_off, d_xs, d_df, cap)
+
+        def step_and_gather(_last):
+            plain_step()
             exchange_payload()
-        torch.cuda.synchronize()
-        dist.barrier()
-        e2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=cdev)
-        dist.all_reduce(e2, op=dist.ReduceOp.MAX)
-        e2 = float(e2.item())
+        e2 = timed_window(K2, step_and_gather)
+        every_ok = xch.verify(d_off, d_xs, d_df)
         g_every = {"value": round(world * B * K2 / e2, 1), "unit": "frames/s", "steps": K2,
-                   "ms_per_step": round(e2 / K2 * 1e3, 4), "gather_ms": round(gstat["ms"] / max(gstat["calls"], 1), 4),
-                   "gather_bytes": gstat["bytes"] // max(gstat["calls"], 1),
-                   "gather_gbps": round(gstat["bytes"] / max(gstat["ms"], 1e-9) / 1e6, 1),
+                   "ms_per_step": round(e2 / K2 * 1e3, 4), "gather_ms": round(xch.ms / max(xch.calls, 1), 4),
+                   "gather_bytes": xch.bytes // max(xch.calls, 1),
+                   "gather_gbps": round(xch.bytes / max(xch.ms, 1e-9) / 1e6, 1), "gather_verified": every_ok,
                    "note": "every batch's changed-pixel stream of every rank gathered to rank 0 (rank 0's own timing of "
                            "mi355_group_gather, host synchronised either side)"}
+        if rank == 0 and every_ok is False:
+            gather_verified = False
+    core.synchronize()
     off = d_off.cpu().numpy().view(np.uint32)
     p_total = int(off[-1])
     assert p_total <= cap, "output capacity too small for this stream"
 
-    # Did the root receive what the ranks produced?  (Outside every timed region.)  The last thing every rank did was a
-    # gather of its latest batch: every rank digests its own (offsets, xs, diff), the digests travel over
-    # torch.distributed, rank 0 digests the segment it holds for every rank.
-    gather_verified = None
-    if group is not None:
-        def digest(o, xs, df):
-            pn = int(o[-1].item()) & 0xFFFFFFFF
-            w = torch.arange(pn, device=dev, dtype=torch.int64) % 8191 + 1
-            return [pn, int(o.to(torch.int64).sum().item()), int((xs[:pn].to(torch.int64) * w).sum().item()),
-                    int((df[:pn].to(torch.int64) * w).sum().item())]
-        core.synchronize()
-        mine_d = torch.tensor(digest(d_off, d_xs, d_df), dtype=torch.int64, device=cdev)
-        all_d = [torch.zeros_like(mine_d) for _ in range(world)]
-        dist.all_gather(all_d, mine_d)
-        if rank == 0:
-            gather_verified, at = True, 0
-            for r in range(world):
-                pn = int(all_d[r][0].item())
-                got = digest(r_off[r], r_xs[at:], r_df[at:]) if at + pn <= r_xs.numel() else None
-                gather_verified = gather_verified and got == [int(v) for v in all_d[r].tolist()]
-                at += pn
+    # BASELINE configs[4] across the ranks of this job (whenever a launcher started it: N > 1, or N = 1 with real RCCL)
+    c5 = None
+    if dist is not None and not args.no_config5 and not rr:
+        c5 = config5_across_ranks(args, dist, world, rank, local_rank, dev, cdev, rehearse)
 
     if rank == 0:
         alg_bytes = 2.0 * n * B + 5.0 * p_total          # SURVEY.md 8d: B_alg = 2N + 5P per frame
@@ -747,13 +842,16 @@ def main():
                                             "value_with_final_gather); --gather last puts it inside the timed region",
                                    "last": "last: one gather-v of the final batch to rank 0 inside the timed region"}.get(args.gather, args.gather)
                                   if dist is not None else "n/a"), "gather_impl": gather_impl},
+            # (the K steps + the job's one exchange, MAX over the ranks: `value` has only the steps in its denominator)
             **({"value_with_final_gather": round(world * B * K / (elapsed + gather_after_s), 1),
                 "final_gather_ms": round(gather_after_s * 1e3, 4)} if gather_after_s is not None else {}),
             "ranks_seen": g_last["ranks_seen"],
             "gather_ms": round(g_last["ms"] / g_last["calls"], 4) if g_last["calls"] else None,
             "gather_bytes": g_last["bytes"] // g_last["calls"] if g_last["calls"] else None,
+            "gather_ran": bool(g_last["calls"]) if dist is not None else None,
             "gather_every": g_every,
             "gather_verified": gather_verified,
+            **({"config5": c5} if c5 is not None else {}),
             "roofline": path_roofline(alg_bytes, (ms_pack, ms_scan, ms_expand), launches, rr, pmc,
                                       wall_ms=elapsed / K * 1e3 if pipelined else None),
         }
@@ -763,12 +861,18 @@ def main():
                                    "ms_per_step": round(s3 / k3 * 1e3, 4),
                                    "achieved_gbps": round(alg_bytes / (s3 / k3) / 1e9, 1),   # per GPU (rank 0's bytes)
                                    "frac": round(alg_bytes / (s3 / k3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                   "actual_gbps": (round(pmc["hbm_bytes_per_launch"] / (s3 / k3) / 1e9, 1) if pmc else None),
+                                   **fractions(alg_bytes, pmc["hbm_bytes_per_launch"] if pmc else None, s3 / k3, rr),
                                    "note": "the same step repeated right behind the K timed steps, wall clock between device "
-                                           "synchronisations: what the path sustains once the chip has reached its clocks "
-                                           "(a short timed region sits on the ramp: DESIGN.md section 8).  frac is on the "
-                                           "ALGORITHMIC 2N + 5P like the headline's (the state stays in registers: the chip "
-                                           "moves 0.69 of them, actual_gbps -- so frac can pass 1 on a cool chip)"}
+                                           "synchronisations: what the path sustains (DESIGN.md section 8)"}
+        if cold is not None:
+            out["cold_start_window"] = {"value": round(world * B * K / cold, 1), "ms_per_step": round(cold / K * 1e3, 4),
+                                        "frac": round(alg_bytes / (cold / K) / 1e9 / HBM_PEAK_GBPS, 4),
+                                        "note": f"the same {args.warmup} warm-up + {K} timed steps as the FIRST GPU work of the process "
+                                                "(what rounds 1-5 printed as `value`): it sits on the chip's clock ramp"}
+        out["preheat"] = {"seconds": args.preheat_s, "steps": preheat_steps,
+                          "note": "the same step, untimed, in front of the warm-up + timed steps whose rate is `value`: a chip that "
+                                  "has been idle needs ~12 ms of load to reach its clocks and ~0.3 s to its sustained state "
+                                  "(profiles/r05ao-r05as); --preheat-s 0: none"}
         if world == 1 and not args.no_pair and not rr:
             out["pair_mode"] = pair_mode(args, core, frames, d_off, d_xs, d_df, cap, n)
             out["regimes"] = regimes(args, dev)
@@ -783,6 +887,11 @@ def main():
         out["board"] = board_fingerprint(core, "right after the timed region")
         out["board"]["rocm_smi_before"] = smi_before
         out["board"]["rocm_smi_after"] = smi_snapshot()
+        stream_gbps = out["board"].get("hbm_stream_read_gbps")
+        if stream_gbps:
+            for blk in (out["roofline"], out.get("steady_state")):
+                if blk and blk.get("actual_gbps"):
+                    blk["frac_of_achievable"] = round(blk["actual_gbps"] / stream_gbps, 4)
         parity_failed = False
         if world == 1 and not args.no_cpu and not rr:
             out["cpu_baseline"], headline_ok = cpu_baseline(args, base, frames, dev)
@@ -796,14 +905,22 @@ def main():
             parity_failed = not all(par.values())
         else:
             out["cpu_baseline"] = None
+        if c5 is not None and "parity" in c5:
+            out["parity"] = dict(out.get("parity") or {}, config5=c5["parity"])
+            parity_failed = parity_failed or c5["parity"] is not True
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
         if parity_failed:
-            print(f"bench.py: PARITY FAILED: {out['parity']}", file=sys.stderr)
+            print(f"bench.py: PARITY FAILED: {out.get('parity')}", file=sys.stderr)
             core.close()
             raise SystemExit(4)
+        if gather_verified is False or (c5 is not None and c5.get("gather_verified") is False):
+            print("bench.py: GATHER NOT VERIFIED: the root's copy of a rank's batch differs from what that rank produced",
+                  file=sys.stderr)
+            core.close()
+            raise SystemExit(5)
     if group is not None:
         group.close()
     core.close()
@@ -1036,6 +1153,108 @@ def config5_per_gpu(args, dev, ranks=8, B=64, W=3840, H=2160, reps=10):
         return out
     except Exception as e:   # noqa: BLE001  -- a secondary line must not cost the bench line (memory on a shared box)
         return {"skipped": repr(e)[:160]}
+
+
+def config5_across_ranks(args, dist, world, rank, local_rank, dev, cdev, rehearse):
+    """BASELINE configs[4] as the job itself: ONE 3840x2160 S1 sequence dealt round-robin over the ranks that are actually
+    there (rank r takes frames r, r + world, ...: a 64-frame shard each), every frame diffed against its raw predecessor,
+    stateless (mi355_diff_pairs_batch: the shards need nothing of each other), then the path's one exchange: gather-v of
+    every rank's changed-pixel stream to rank 0 over RCCL (mi355_group_gather on a group of its own).  Timed like the
+    headline: K passes over the shard between barriers, MAX over the ranks; the gather behind them, timed on its own.
+    Parity: rank 0 looks at ITS copy of the gathered streams -- for every rank the first and the last frame of that rank's
+    shard -- against the oracle's diff of the regenerated frames: kernel, gather and the round-robin bookkeeping in one check.
+    Every rank takes part in every collective here; only rank 0's return value is used."""
+    W, H, B = args.config5_size
+    K5 = max(args.config5_steps, 1)
+    n = 3 * W * H
+    seed = 31
+    res = {"workload": f"BASELINE configs[4]: {W}x{H} BGR24 S1 sequence of {B * world} frames dealt round-robin over {world} rank(s), "
+                       f"{B}-frame shards resident in HBM, stateless diff against the raw predecessor + threshold(20) + pack, "
+                       f"then ONE gather-v of all shards' streams to rank 0",
+           "frames_per_rank": B, "steps": K5}
+    mine = gx.roundrobin_frames(rank, world, B * world)
+    frames = torch.stack([synth.webcam_frame(t, W, H, seed=seed, device=dev) for t in mine])
+    prevs = torch.stack([synth.webcam_frame(t - 1, W, H, seed=seed, device=dev) for t in mine])
+    cap = max(B * n // 8, 1 << 20)
+    d_off = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    d_xs = torch.empty(cap, dtype=torch.int32, device=dev)
+    d_df = torch.empty(cap, dtype=torch.uint8, device=dev)
+    core = CUDACore(W, H, max_batch=B, device=local_rank)
+    torch.cuda.synchronize()
+    group, impl = form_group(core, dist, world, rank, local_rank, cdev, rehearse)
+    res["gather_impl"] = impl
+    xch = Exchange(group, dist, world, rank, B, cap, dev, cdev)
+
+    def step():
+        core.diff_pairs_batch(frames, prevs, B, d_off, d_xs, d_df, cap)
+
+    warm_up(core, step, 3)
+    xch.run(d_off, d_xs, d_df)     # RCCL sets up this communicator's peer channels on first use
+    xch.reset()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K5):
+        step()
+    core.synchronize()
+    torch.cuda.synchronize()
+    mine_s = time.perf_counter() - t0
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    p = int(d_off[B].item()) & 0xFFFFFFFF
+    assert p <= cap, "config5: output capacity too small"
+    # per rank: its own seconds for the K passes, its changed bytes
+    mine_t = torch.tensor([mine_s, float(p)], dtype=torch.float64, device=cdev)
+    every = [torch.zeros_like(mine_t) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(every, mine_t)
+    else:
+        every = [mine_t]
+    # the exchange, behind the timed passes (barrier + synchronisation either side, MAX over the ranks)
+    dist.barrier()
+    torch.cuda.synchronize()
+    tg = time.perf_counter()
+    xch.run(d_off, d_xs, d_df)
+    dist.barrier()
+    eg = torch.tensor([time.perf_counter() - tg], dtype=torch.float64, device=cdev)
+    dist.all_reduce(eg, op=dist.ReduceOp.MAX)
+    gather_s = float(eg.item())
+    verified = xch.verify(d_off, d_xs, d_df)
+    if rank == 0:
+        from oracle import pyoracle as po
+        index, xs_all, df_all = xch.root
+        seg = gx.roundrobin_order(index, B * world)     # global frame t -> its entries inside the rank-major gathered arrays
+        ok = True
+        for r in range(world):
+            for k in sorted({0, B - 1}):
+                t = r + k * world
+                cur = synth.webcam_frame(t, W, H, seed=seed, device=dev).cpu().numpy()
+                prv = synth.webcam_frame(t - 1, W, H, seed=seed, device=dev).cpu().numpy()
+                cnt, xs, df, _ = po.diff_pack(cur, prv)
+                a, b = seg[t]
+                ok = ok and b - a == cnt and np.array_equal(xs_all[a:b].cpu().numpy(), xs) and np.array_equal(df_all[a:b].cpu().numpy(), df)
+        fr = [2.0 * n * B + 5.0 * float(e[1].item()) for e in every]
+        res.update({
+            "value": round(world * B * K5 / elapsed, 1), "unit": "frames/s", "ms_per_step": round(elapsed / K5 * 1e3, 4),
+            "changed_bytes_per_frame": round(sum(float(e[1].item()) for e in every) / (B * world), 1),
+            "frac_per_rank": [round(fr[r] / (float(every[r][0].item()) / K5) / 1e9 / HBM_PEAK_GBPS, 4) for r in range(world)],
+            "frac": round(sum(fr) / world / (elapsed / K5) / 1e9 / HBM_PEAK_GBPS, 4),
+            "final_gather_ms": round(gather_s * 1e3, 4), "gather_ms": round(xch.ms / max(xch.calls, 1), 4),
+            "gather_bytes": xch.bytes // max(xch.calls, 1),
+            "gather_gbps": round(xch.bytes / max(xch.ms, 1e-9) / 1e6, 1),
+            "value_with_final_gather": round(world * B * K5 / (elapsed + gather_s), 1),
+            "ranks_seen": xch.ranks_seen, "gather_verified": verified, "parity": bool(ok),
+            "basis": "value / ms_per_step / frac: K passes over every rank's shard between barriers, MAX over the ranks (frac: the "
+                     "ranks' mean algorithmic 2N + 5P bytes per pass over that time, per GPU, of 8 TB/s; frac_per_rank: each rank's "
+                     "own clock); final_gather_ms: the one gather behind them, barrier to barrier, MAX over the ranks; gather_ms / "
+                     "gather_gbps: rank 0's own timing of the call and the bytes that arrived at it; parity: rank 0's copy of the "
+                     "first and last frame of every rank's shard against the oracle"})
+    if group is not None:
+        group.close()
+    core.close()
+    return res if rank == 0 else None
 
 
 def regimes(args, dev, B=32):

@@ -114,6 +114,11 @@ class CUDACore:
     def workspace_bytes(self):
         return self._lib.mi355_workspace_bytes(self._h)
 
+    def prepare(self, what=_l.PREPARE_ALL):
+        """mi355_prepare: make now what the entry points would otherwise make on first use (lib.PREPARE_*), so that no
+        asynchronous call allocates."""
+        _l.check(self._lib.mi355_prepare(self._h, int(what)))
+
     def use_torch_stream(self):
         """Enqueue on PyTorch's current stream (0 = the default stream), so torch ops, events and
         collectives issued on it are ordered with the core's kernels."""

@@ -62,7 +62,7 @@ struct mi355_core {
     uint4 *rec = nullptr, *meta = nullptr;
     uint32_t *codes = nullptr;
     uint32_t *groff = nullptr, *totals = nullptr;   // totals: T tagged 64-bit words + the scan kernel's ticket (2T + 2 words)
-    uint32_t scan_epoch = 0;      // tag of the last k_scan_groups launch (diff_pack.hip, publish_total)
+    uint64_t scan_epoch = 0;      // tag of the last k_scan_groups launch, 1 .. kEpochWrap - 1 (internal.h, next_scan_epoch)
     uint32_t *offsets = nullptr;  // T+1, used by exec()
     int32_t *one_xs = nullptr;
     uint8_t *one_diff = nullptr;
@@ -246,7 +246,13 @@ int need_gray1(mi355_core *c) {
     return dev_alloc(c, &c->gray1, c->gray1_stride * (size_t)c->cfg.max_batch);
 }
 
-// The second set of logs and the side stream of the pipelined mode, made when it is first used.
+// Slice bounds of the cleared red map (mi355_red_stream_batch, clear != 0), max_batch frames: made when first needed.
+int need_red_bounds(mi355_core *c) {
+    if (c->red_bounds || c->n == 0) return MI355_OK;
+    return dev_alloc(c, &c->red_bounds, (size_t)c->cfg.max_batch * red_bounds_per_frame(c->n));
+}
+
+// The second set of logs and the side stream of the pipelined mode, made when it is first used (or by mi355_prepare).
 int setup_pipeline(mi355_core *c) {
     if (c->side || !c->pipeline_ok) return MI355_OK;
     // Pipelined batches: the pack kernel on 4 workgroups per CU (16 waves: half of them walk a second tile) instead of
@@ -292,6 +298,12 @@ int setup_pipeline(mi355_core *c) {
         s1.rec = nullptr; s1.meta = nullptr; s1.codes = s1.groff = s1.totals = nullptr;
         if (c->side) { (void)hipStreamDestroy(c->side); c->side = nullptr; }
         if (c->main2) { (void)hipStreamDestroy(c->main2); c->main2 = nullptr; }
+        // ... and what a later attempt (MI355_OPT_PIPELINE 1 switches the mode on again) would otherwise overwrite
+        if (c->h_tot) { (void)hipHostFree(c->h_tot); c->h_tot = nullptr; }
+        for (int i = 0; i < mi355_core::kSets; i++) {
+            hipEvent_t *evs[] = {&c->set[i].packed, &c->set[i].expanded, &c->packed2[i], &c->fork[i]};
+            for (hipEvent_t *e : evs) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+        }
         c->pipeline_ok = false;
         return MI355_OK;
     }
@@ -425,7 +437,16 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
         HIP_TRY(hipStreamWaitEvent(tail, ls.packed, 0));
     }
     if (tev) HIP_TRY(hipEventRecord(tev[2], tail));
-    if (++c->scan_epoch == 0) c->scan_epoch = 1;
+    if (next_scan_epoch(c->scan_epoch)) {
+        // the launch tags have wrapped (2^33 launches): every total any launch of this core has written goes, behind a
+        // synchronisation, before a tag is used a second time -- a slot can then never hold a stale word with a current tag
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->side) HIP_TRY(hipStreamSynchronize(c->side));
+        if (c->main2) HIP_TRY(hipStreamSynchronize(c->main2));
+        const size_t words = 2 * (size_t)c->cfg.max_batch * sizeof(uint32_t);   // (the ticket behind them is 0 between launches)
+        HIP_TRY(hipMemset(c->totals, 0, words));
+        if (c->set[1].totals) HIP_TRY(hipMemset(c->set[1].totals, 0, words));
+    }
     // (an own-stream batch leaves its total in pinned memory for the next calls' decisions -- stored by the index kernel
     // itself: a copy + an event behind every batch cost config 3's chain 4 %, the event's system-scope fence included)
     uint64_t *const note = own && c->h_tot && c->pipeline_ok && c->dense_pct > 0 && c->dense_pct < 100 ? c->h_tot : nullptr;
@@ -536,6 +557,8 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
         e = hipMemcpy(c->lut, lut, sizeof lut, hipMemcpyHostToDevice);
         if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipMemcpy(lut)", e);
     }
+    // what a per-frame server's first exec() would otherwise allocate (kernels.cu:493-498: visualiser 5)
+    if (!rc && cfg->visualizer == MI355_VIS_BINARIZE) rc = need_gray1(c);
     if (rc) { mi355_destroy(c); return rc; }
     *out = c;
     return MI355_OK;
@@ -568,6 +591,23 @@ void mi355_destroy(mi355_core *c) {
     for (auto &slot : c->ev) for (auto &ev : slot) if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
+}
+
+int mi355_prepare(mi355_core *c, unsigned what) {
+    if (!c) return fail(MI355_ERR_INVALID, "null core");
+    if (what & ~MI355_PREPARE_ALL) return fail(MI355_ERR_INVALID, "mi355_prepare: unknown bit in `what`");
+    if (int rc = use_device(c)) return rc;
+    if ((what & MI355_PREPARE_BATCHES) && c->n > 0) {
+        if (int rc = setup_pipeline(c)) return rc;   // (a core that cannot have its second set stays sequential: not an error)
+    }
+    if (what & MI355_PREPARE_GRAY_CHAIN)
+        if (int rc = need_gray1(c)) return rc;
+    if (what & MI355_PREPARE_RED_CLEAR)
+        if (int rc = need_red_bounds(c)) return rc;
+    if ((what & MI355_PREPARE_CONV_KXK) && !c->kxk)
+        if (int rc = dev_alloc(c, &c->kxk, 81)) return rc;
+    HIP_TRY(hipDeviceSynchronize());   // the memsets of the new buffers
+    return MI355_OK;
 }
 
 size_t mi355_frame_bytes(const mi355_core *c) { return c ? c->n : 0; }
@@ -641,6 +681,11 @@ int mi355_set_option(mi355_core *c, int option, int value) {
             if (value < 0 || value > 60 || value % 5) return fail(MI355_ERR_INVALID, "MI355_OPT_MEDIAN_ROWS: 0 (default) or 5, 10, .. 60");
             c->median_rows = value;
             return MI355_OK;
+        case MI355_OPT_SCAN_EPOCH_LEFT:   // tests: the index kernel's launch tag this many launches before its wrap
+            if (value < 1 || value > (1 << 30)) return fail(MI355_ERR_INVALID, "MI355_OPT_SCAN_EPOCH_LEFT: 1..2^30");
+            if (c->side) HIP_TRY(hipStreamSynchronize(c->side));
+            c->scan_epoch = kEpochWrap - 1 - (uint64_t)value;
+            return MI355_OK;
         default: return fail(MI355_ERR_INVALID, "unknown option");
     }
 }
@@ -654,6 +699,11 @@ int mi355_get_option(mi355_core *c, int option, int *value) {
         case MI355_OPT_CHAIN_HINT: *value = c->chain_hint ? 1 : 0; return MI355_OK;
         case MI355_OPT_PACK_BLOCKS: *value = c->pack_blocks_opt; return MI355_OK;
         case MI355_OPT_MEDIAN_ROWS: *value = c->median_rows; return MI355_OK;
+        case MI355_OPT_SCAN_EPOCH_LEFT: {
+            const uint64_t left = kEpochWrap - 1 - c->scan_epoch;
+            *value = left > (1ull << 30) ? (1 << 30) : (int)left;
+            return MI355_OK;
+        }
         default: return fail(MI355_ERR_INVALID, "unknown option");
     }
 }
@@ -858,8 +908,8 @@ int mi355_red_stream_batch(mi355_core *c, const void *d_offsets, const void *d_x
     if (int rc = use_device(c)) return rc;
     // only the cleared form needs per-frame scratch (slice bounds), which is sized for max_batch frames
     if (clear && nframes > c->cfg.max_batch) return fail(MI355_ERR_INVALID, "nframes outside [0, max_batch]");
-    if (clear && !c->red_bounds)
-        if (int rc = dev_alloc(c, &c->red_bounds, (size_t)c->cfg.max_batch * red_bounds_per_frame(c->n))) return rc;
+    if (clear)
+        if (int rc = need_red_bounds(c)) return rc;
     HIP_TRY(launch_red_stream((uint8_t *)d_frames, (const uint32_t *)d_offsets, (const int32_t *)d_xs, c->n, clear != 0,
                               FrameBatch{stride_bytes, nframes}, c->stream, c->red_bounds));
     return MI355_OK;

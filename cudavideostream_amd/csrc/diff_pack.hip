@@ -414,14 +414,16 @@ constexpr uint32_t kScanDepth = 24;       // groups a wave of k_scan_groups has 
 // fence instead writes back this XCD's whole L2 -- full of the next batch's fresh log lines when batches are pipelined
 // -- 19 us instead of 12 us per launch, profiles/README.md.)  The writer has issued its store before it takes its
 // ticket, so the reader's wait is bounded by that store's flight time; no workgroup waits for one that has not started.
-__device__ __forceinline__ void publish_total(uint64_t *slot, uint32_t total, uint32_t epoch) {
-    __hip_atomic_store(slot, (uint64_t)total | ((uint64_t)epoch << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Round 6: the word is {total: 31 bits, tag: 33 bits} (a frame is below 2 GiB, mi355_create), and the host clears the
+// totals when the tag wraps (internal.h, next_scan_epoch): the argument no longer rests on a counter's width.
+__device__ __forceinline__ void publish_total(uint64_t *slot, uint32_t total, uint64_t epoch) {
+    __hip_atomic_store(slot, (uint64_t)total | (epoch << kTotalBits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ uint32_t read_total(const uint64_t *slot, uint32_t epoch) {
+__device__ __forceinline__ uint32_t read_total(const uint64_t *slot, uint64_t epoch) {
     uint64_t v;
     do v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while ((uint32_t)(v >> 32) != epoch);
-    return (uint32_t)v;
+    while ((v >> kTotalBits) != epoch);
+    return (uint32_t)v & ((1u << kTotalBits) - 1u);
 }
 
 // grid = T, block = 256: roff[t][r] = flagged bytes of frame t in the 16-tile ranges before r (4 per group),
@@ -432,7 +434,7 @@ __device__ __forceinline__ uint32_t read_total(const uint64_t *slot, uint32_t ep
 // into offsets[0..T]: one launch and one dependent round trip less than a separate kernel.
 __global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t *roff, uint64_t *totals,
                                                      uint32_t ntiles, uint32_t ngroups, uint32_t *ticket,
-                                                     uint32_t epoch, uint32_t *offsets, uint64_t *note) {
+                                                     uint64_t epoch, uint32_t *offsets, uint64_t *note) {
     static_assert(kXTiles == 64, "one wave reduces one group");
     __builtin_amdgcn_s_setprio(3);   // pipelined batches: this short kernel gates the expansion; it must not queue for
                                      // issue slots behind the next batch's pack waves
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(256) void k_scan_groups(const uint4 *meta, uint32_t
 uint32_t expand_groups(uint32_t ntiles) { return (ntiles + kXTiles - 1) / kXTiles; }
 
 hipError_t launch_scan(const uint4 *meta, uint32_t *roff, uint64_t *totals, uint32_t ntiles,
-                       int nframes, uint32_t *offsets, uint32_t *ticket, uint32_t epoch, uint64_t *note, hipStream_t s) {
+                       int nframes, uint32_t *offsets, uint32_t *ticket, uint64_t epoch, uint64_t *note, hipStream_t s) {
     hipLaunchKernelGGL(k_scan_groups, dim3(nframes), dim3(256), 0, s, meta, roff, totals, ntiles,
                        expand_groups(ntiles), ticket, epoch, offsets, note);
     return hipGetLastError();

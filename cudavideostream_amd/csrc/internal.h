@@ -59,9 +59,21 @@ int core_device(const ::mi355_core *c);
 hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, bool pair_once /* pair mode: no frame is an operand twice */,
                             uint32_t max_blocks /* 0: one tile per wave */, hipStream_t s);
 uint32_t expand_groups(uint32_t ntiles);
-hipError_t launch_scan(const uint4 *meta, uint32_t *roff, uint64_t *totals /* [T] {total, epoch} */, uint32_t ntiles,
+// A frame total travels as ONE 64-bit word {total: 31 bits (a frame is below 2 GiB), tag of the launch: 33 bits}
+// (diff_pack.hip, publish_total).  The tag counts the launches of a core and is never 0 (0 = never written); when it
+// would wrap the host clears every total behind a synchronisation (core.hip, next_scan_epoch), so a slot can never
+// carry a stale word with the current tag, whatever the number of launches.
+constexpr int kTotalBits = 31;
+constexpr uint64_t kEpochWrap = 1ull << (64 - kTotalBits);   // tags are 1 .. kEpochWrap - 1
+// the tag of the next launch; true: the tags have wrapped, the caller must clear the totals before that launch
+inline bool next_scan_epoch(uint64_t &epoch) {
+    if (++epoch < kEpochWrap) return false;
+    epoch = 1;
+    return true;
+}
+hipError_t launch_scan(const uint4 *meta, uint32_t *roff, uint64_t *totals /* [T] {total, tag} */, uint32_t ntiles,
                        int nframes, uint32_t *offsets, uint32_t *ticket /* zero between launches */,
-                       uint32_t epoch /* != 0, different from the launch that last wrote `totals` */,
+                       uint64_t epoch /* 1 .. kEpochWrap - 1, different from every tag `totals` still holds */,
                        uint64_t *note /* pinned host word for {batch total, frames << 32}, or nullptr */, hipStream_t s);
 hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s);
 

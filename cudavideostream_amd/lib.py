@@ -21,7 +21,9 @@ VIS_NONE, VIS_HEAT, VIS_RED, VIS_RED_OVERLAP, VIS_GRAY, VIS_BINARIZE = range(6)
 (OP_GRAY_AVG, OP_GRAY_WEIGHTED, OP_BINARIZE, OP_GRAY_AVG_BINARIZE, OP_GRAY_WEIGHTED_BINARIZE, OP_HEAT_MAP,
  OP_RED_DENSE, OP_CONV3X3, OP_MEDIAN5X5) = range(1, 10)
 
-OPT_PIPELINE, OPT_SPLIT_PCT, OPT_DENSE_PCT, OPT_CHAIN_HINT, OPT_PACK_BLOCKS, OPT_MEDIAN_ROWS = range(1, 7)   # MI355_OPT_*
+(OPT_PIPELINE, OPT_SPLIT_PCT, OPT_DENSE_PCT, OPT_CHAIN_HINT, OPT_PACK_BLOCKS, OPT_MEDIAN_ROWS,
+ OPT_SCAN_EPOCH_LEFT) = range(1, 8)   # MI355_OPT_*
+PREPARE_BATCHES, PREPARE_GRAY_CHAIN, PREPARE_RED_CLEAR, PREPARE_CONV_KXK, PREPARE_ALL = 1, 2, 4, 8, 15   # MI355_PREPARE_*
 
 
 class Config(C.Structure):
@@ -45,6 +47,7 @@ SYMBOLS = {
     "mi355_abi_version": (C.c_int, []),
     "mi355_frame_bytes": (C.c_size_t, [C.c_void_p]),
     "mi355_workspace_bytes": (C.c_size_t, [C.c_void_p]),
+    "mi355_prepare": (C.c_int, [C.c_void_p, C.c_uint]),
     "mi355_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi355_use_own_stream": (C.c_int, [C.c_void_p]),
     "mi355_synchronize": (C.c_int, [C.c_void_p]),
@@ -122,7 +125,7 @@ SYMBOLS = {
     "mi355_group_synchronize": (C.c_int, [C.c_void_p]),
 }
 GROUP_ID_BYTES = 128   # MI355_GROUP_ID_BYTES
-ABI_VERSION = 5        # MI355_ABI_VERSION of the include/mi355diff.h these argument lists were written against
+ABI_VERSION = 6        # MI355_ABI_VERSION of the include/mi355diff.h these argument lists were written against
 
 _lib = None
 

@@ -63,8 +63,9 @@ typedef struct mi355_config {
  *   5  round 5: + mi355_set_option / mi355_get_option; MI355_FLAG_FUSED / MI355_FLAG_CHAIN (two opt-in experiments) are
  *      gone and cfg.flags must be 0; the environment variables MI355_SPLIT, MI355_DENSE_PCT, MI355_CHAIN_HINT and the
  *      undocumented tuning variables are no longer read (options below); + MI355_OPT_MEDIAN_ROWS, mi355_probe_hbm_write
- *      (additions) */
-#define MI355_ABI_VERSION 5
+ *      (additions)
+ *   6  round 6: + mi355_prepare, MI355_OPT_SCAN_EPOCH_LEFT (additions only) */
+#define MI355_ABI_VERSION 6
 int mi355_abi_version(void);
 
 /* ---- life cycle: CUDACore::CUDACore (kernels.cu:377-428) without the uploads ------------------ */
@@ -77,8 +78,24 @@ size_t mi355_frame_bytes(const mi355_core *core);
  * of every frame of a batch changed): about (1 + 1/3) * max_batch * N bytes, 2.07 GB for 1080p and max_batch 256.  The
  * first asynchronous batch call on the core's own stream allocates a second set (hipMalloc + hipMemset inside that
  * call: it is not asynchronous) for the pipelined mode below; scratch buffers of the fused gray+binarize chain and of
- * the cleared red map are likewise allocated by the first call that needs them. */
+ * the cleared red map are likewise allocated by the first call that needs them -- unless mi355_prepare has made them. */
 size_t mi355_workspace_bytes(const mi355_core *core);
+/* Makes NOW what the entry points would otherwise make on first use -- so that no hipMalloc / hipMemset / stream or event
+ * creation happens inside an asynchronous entry point and a server's first frames do not stall.  `what` is a mask:
+ *   MI355_PREPARE_BATCHES      second set of logs, side streams and events of pipelined own-stream batches
+ *                              (mi355_diff_stream_batch / _pairs_batch / _wire_batch on the core's own stream);
+ *   MI355_PREPARE_GRAY_CHAIN   one gray byte per pixel for max_batch frames (MI355_OP_GRAY_*_BINARIZE, MI355_VIS_BINARIZE);
+ *   MI355_PREPARE_RED_CLEAR    slice bounds of mi355_red_stream_batch(clear != 0);
+ *   MI355_PREPARE_CONV_KXK     the tap buffer of mi355_conv_kxk.
+ * mi355_create already makes the one a per-frame server needs (MI355_VIS_BINARIZE's gray bytes).  Blocking; idempotent;
+ * mi355_workspace_bytes grows by what was made.  After mi355_prepare(core, MI355_PREPARE_ALL) no entry point of the core
+ * allocates (mi355_pipe_open and mi355_set_glyphs, which say so, excepted). */
+#define MI355_PREPARE_BATCHES 1u
+#define MI355_PREPARE_GRAY_CHAIN 2u
+#define MI355_PREPARE_RED_CLEAR 4u
+#define MI355_PREPARE_CONV_KXK 8u
+#define MI355_PREPARE_ALL 15u
+int mi355_prepare(mi355_core *core, unsigned what);
 
 /* Streams.  A core starts on a stream of its own, created hipStreamNonBlocking: it is NOT ordered against the
  * legacy default stream nor against any other stream of the caller.  Buffers the caller fills asynchronously on
@@ -116,6 +133,8 @@ int mi355_synchronize(mi355_core *core);
 #define MI355_OPT_MEDIAN_ROWS 6  /* 0 (default): the 5x5 median's column-strip kernel walks bands of 5..60 rows, chosen per launch
                                   * (from 20 rows up the length that wastes least of the frame's last pair of bands; shorter
                                   * when that makes fewer than a few thousand waves); 5, 10, .. 60: this many */
+#define MI355_OPT_SCAN_EPOCH_LEFT 7 /* tests only: launches of the index kernel left before its 33-bit launch tag wraps (the
+                                  * totals are then cleared behind a synchronisation and the tag restarts at 1); set: 1..2^30 */
 int mi355_set_option(mi355_core *core, int option, int value);
 int mi355_get_option(mi355_core *core, int option, int *value);
 

@@ -98,3 +98,21 @@ def test_product_does_not_import_oracle():
                     assert not banned.search(text), f"{os.path.join(dirpath, f)} references the oracle"
     out = subprocess.run(["ldd", lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_scan_epoch_arithmetic_on_the_host(tmp_path):
+    """The index kernel's launch tags (csrc/internal.h): 1 .. 2^33 - 1, never 0, the wrap is signalled (the host then clears
+    the totals: core.hip), and a 31-bit total + 33-bit tag share one 64-bit word.  The GPU half of the wrap path is
+    tests/test_diff_pack_gpu.py::test_scan_epoch_wrap_clears_the_totals."""
+    exe = tmp_path / "epoch_check"
+    subprocess.run(["g++", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                    "-I" + os.path.join(ROOT, "cudavideostream_amd", "csrc"), os.path.join(ROOT, "tests", "host", "epoch_check.cpp"),
+                    "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("ok 8589934592"), (r.returncode, r.stdout)
+
+
+def test_prepare_validates_its_arguments_without_gpu(built):
+    from cudavideostream_amd import lib
+    L = lib.load()
+    assert L.mi355_prepare(None, lib.PREPARE_ALL) == lib.ERR_INVALID

@@ -405,6 +405,86 @@ def test_heavy_record_count_per_wave(po, heavy):
 
 
 # ---- pipelined batches: expansion of batch k beside the pack kernel of batch k + 1 (own stream) ---------------------------
+def _check_batches_against_oracle(outs, eo, exs, edf, T):
+    per_frame = np.diff(eo.astype(np.int64))
+    at = 0
+    for k, (o, x, d) in enumerate(outs):
+        cnt = per_frame[k * T:(k + 1) * T]
+        off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint32)
+        tot = int(off[-1])
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), off), k
+        assert np.array_equal(x[:tot].cpu().numpy(), exs[at:at + tot]), k
+        assert np.array_equal(d[:tot].cpu().numpy(), edf[at:at + tot]), k
+        at += tot
+
+
+@pytest.mark.parametrize("own_stream", [True, False])
+def test_scan_epoch_wrap_clears_the_totals(po, own_stream):
+    """The index kernel's frame totals travel as {total: 31 bits, launch tag: 33 bits}; when the tag wraps (2^33 launches) the
+    host clears every total behind a synchronisation before a tag is used again (core.hip, next_scan_epoch).  Forced here:
+    the tag is put 3 launches before its wrap (MI355_OPT_SCAN_EPOCH_LEFT), nine batches run across it back to back -- on
+    the core's own stream (pipelined, two sets of totals) and on a caller's -- and every batch must equal the oracle."""
+    from cudavideostream_amd import lib as L
+    w, h, T, K = 320, 180, 4, 9
+    n = 3 * w * h
+    base, frames = synth.webcam_stream(T * K, w, h, seed=57)
+    eo, exs, edf, est = po.diff_stream(frames, base)
+    d_fr = to_dev(frames)
+    outs = [(torch.zeros(T + 1, dtype=torch.int32, device=DEV), torch.full((T * n,), -7, dtype=torch.int32, device=DEV),
+             torch.zeros(T * n, dtype=torch.uint8, device=DEV)) for _ in range(K)]
+    with CUDACore(w, h, max_batch=T, sample_mat_data=base) as core:
+        if not own_stream:
+            core.use_torch_stream()
+        torch.cuda.synchronize()
+        RawCore.diff_stream_batch(core, d_fr[:T], T, *outs[0], T * n)     # the pipelined mode is set up, both sets of totals exist
+        core.set_option(L.OPT_SCAN_EPOCH_LEFT, 3)
+        assert core.get_option(L.OPT_SCAN_EPOCH_LEFT) == 3
+        for k in range(1, K):
+            RawCore.diff_stream_batch(core, d_fr[k * T:(k + 1) * T], T, *outs[k], T * n)
+        core.synchronize()
+        torch.cuda.synchronize()
+        assert core.get_option(L.OPT_SCAN_EPOCH_LEFT) == (1 << 30)      # wrapped: the tag restarted at 1
+        assert np.array_equal(core.get_state(), est)
+    _check_batches_against_oracle(outs, eo, exs, edf, T)
+
+
+def test_prepare_leaves_nothing_to_allocate(po):
+    """mi355_prepare(MI355_PREPARE_ALL): the second set of logs, the side streams and events of pipelined batches, the gray
+    bytes of the fused binarize chain, the cleared red map's slice bounds and the K x K taps are made NOW; the entry points
+    that would have made them on first use then leave mi355_workspace_bytes where it is (and give the oracle's results)."""
+    from cudavideostream_amd import lib as L
+    w, h, T = 320, 180, 6
+    n = 3 * w * h
+    base, frames = synth.webcam_stream(2 * T, w, h, seed=12)
+    eo, exs, edf, est = po.diff_stream(frames, base)
+    d_fr = to_dev(frames)
+    outs = [(torch.zeros(T + 1, dtype=torch.int32, device=DEV), torch.full((T * n,), -7, dtype=torch.int32, device=DEV),
+             torch.zeros(T * n, dtype=torch.uint8, device=DEV)) for _ in range(2)]
+    vis = torch.empty((T, n), dtype=torch.uint8, device=DEV)
+    with CUDACore(w, h, max_batch=T, sample_mat_data=base) as core:
+        ws0 = core.workspace_bytes
+        core.prepare()
+        ws1 = core.workspace_bytes
+        assert ws1 > ws0 + T * n          # the second record log alone is max_batch frames
+        core.prepare(L.PREPARE_BATCHES | L.PREPARE_GRAY_CHAIN)   # idempotent
+        assert core.workspace_bytes == ws1
+        torch.cuda.synchronize()
+        for k in range(2):                # own stream: pipelined
+            RawCore.diff_stream_batch(core, d_fr[k * T:(k + 1) * T], T, *outs[k], T * n)
+        core.filter_batch(L.OP_GRAY_WEIGHTED_BINARIZE, d_fr[:T], vis, T)
+        core.red_stream_batch(outs[1][0], outs[1][1], T, vis)
+        k5 = np.full(25, 1 / 25, np.float32)
+        one = torch.empty(n, dtype=torch.uint8, device=DEV)
+        core.conv_kxk(d_fr[0], one, k5)
+        core.synchronize()
+        assert core.workspace_bytes == ws1
+        assert np.array_equal(core.get_state(), est)
+    _check_batches_against_oracle(outs, eo, exs, edf, T)
+    with pytest.raises(Exception):
+        with CUDACore(w, h) as core:
+            core.prepare(1 << 9)          # an unknown bit is refused
+
+
 def test_back_to_back_batches_without_synchronisation(po):
     """Seven batches of one stream queued back to back on the core's own stream (the index and the expansion of a
     batch then run on the side stream beside the next batch's pack kernel, two sets of logs in turn), every batch

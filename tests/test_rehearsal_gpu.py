@@ -15,7 +15,21 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MOCK = os.path.join(ROOT, "tests", "mock_rccl", "librccl_mock_ipc.so")
 SMALL = ["--width", "640", "--height", "360", "--batch", "8", "--steps", "3", "--warmup", "2", "--gather-every-steps", "2",
-         "--no-cpu", "--no-pair", "--no-filters", "--no-host-path", "--no-config5"]
+         "--no-cpu", "--no-pair", "--no-filters", "--no-host-path", "--preheat-s", "0.05", "--steady-steps", "20",
+         # BASELINE configs[4] across the ranks of the job, at a size the oracle checks in a moment
+         "--config5-size", "320", "180", "4", "--config5-steps", "2"]
+
+
+def check_config5(line, nranks, rccl):
+    """The config5 object of an N-rank line: the 4K-shaped sequence dealt round-robin over the ranks that are there, the gather
+    to rank 0, rank 0's copy of every rank's first and last frame against the oracle."""
+    c5 = line["config5"]
+    assert c5["parity"] is True and c5["gather_verified"] is True and c5["ranks_seen"] == nranks, c5
+    assert len(c5["frac_per_rank"]) == nranks and all(f > 0 for f in c5["frac_per_rank"])
+    assert c5["value"] > 0 and c5["final_gather_ms"] > 0 and c5["gather_bytes"] > 4 * 5 * nranks and c5["gather_gbps"] > 0
+    assert 0 < c5["value_with_final_gather"] < c5["value"]
+    assert ("RCCL, csrc/group.hip" in c5["gather_impl"]) if rccl else ("REHEARSAL" in c5["gather_impl"])
+    assert line["parity"]["config5"] is True
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +56,10 @@ def test_two_processes_run_the_bench_sequence():
     assert 0 < line["value_with_final_gather"] < line["value"]
     ge = line["gather_every"]
     assert ge["steps"] == 2 and ge["gather_bytes"] > 0 and ge["value"] > 0
+    assert ge["gather_verified"] is True
     assert line["value"] > 0 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["gather_ran"] is True and line["cold_start_window"]["value"] > 0 and line["preheat"]["steps"] > 0
+    check_config5(line, 2, rccl=False)
 
 
 @pytest.mark.skipif(not os.path.exists(MOCK), reason="tests/mock_rccl/librccl_mock_ipc.so not built")
@@ -52,8 +69,14 @@ def test_three_processes_and_a_rank_that_cannot_form_the_group():
     of hanging or measuring something else."""
     r, line = run_bench(["--gpus", "3", "--rehearse-on-one-gpu", "--shard", "roundrobin", "--gather", "last"] + SMALL)
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
-    assert line["ranks_seen"] == 3 and line["gather_verified"] is True
+    assert line["ranks_seen"] == 3 and line["gather_verified"] is True and "config5" not in line   # (--shard roundrobin IS that shape)
     assert line["config"]["gather"].startswith("last") and "value_with_final_gather" not in line   # the exchange inside the timed region
+    # ... and the default job with three ranks: the config5 object with a shard per rank
+    r, line = run_bench(["--gpus", "3", "--rehearse-on-one-gpu"] + SMALL)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    assert line["ranks_seen"] == 3 and line["gather_verified"] is True
+    check_config5(line, 3, rccl=False)
+    assert line["config"]["gather"].startswith("after")
     r, line = run_bench(["--gpus", "2", "--rehearse-on-one-gpu"] + SMALL, env={"MI355_RCCL_LIB": "/nonexistent/librccl.so"})
     err = r.stderr.decode(errors="replace")
     assert r.returncode != 0 and line is None
@@ -76,8 +99,9 @@ def test_one_rank_under_the_launcher_reports_the_gather():
     assert r.returncode == 0 and lines, r.stderr.decode(errors="replace")[-3000:]
     line = json.loads(lines[-1])
     assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["gather_verified"] is True
-    assert line["gather_ms"] is not None and line["gather_bytes"] > 0
+    assert line["gather_ms"] is not None and line["gather_bytes"] > 0 and line["gather_ran"] is True
     assert "RCCL" in line["config"]["gather_impl"] and "rehearsal" not in line
+    check_config5(line, 1, rccl=True)
 
 
 def test_one_rank_whose_group_cannot_be_formed_still_measures_its_steps():
@@ -104,5 +128,11 @@ def test_one_rank_whose_group_cannot_be_formed_still_measures_its_steps():
     assert "forming the group failed in mi355_group_unique_id" in err
     assert line["config"]["gather_impl"].startswith("torch.distributed (mi355_group unavailable")
     assert line["value"] > 0 and line["ranks_seen"] == 1
+    # the exchange DID run (its torch.distributed form, behind the steps, timed the same way), and the steps ran as they do
+    # with a group: on the core's own stream, pipelined
+    assert line["gather_ran"] is True and line["gather_ms"] > 0 and line["final_gather_ms"] > 0 and line["gather_verified"] is True
+    assert "kernel_ms_basis" in line["roofline"]
+    c5 = line["config5"]
+    assert c5["gather_impl"].startswith("torch.distributed (mi355_group unavailable") and c5["parity"] is True and c5["gather_verified"] is True
     r, line = launch(["--gather", "last"])
     assert r.returncode != 0 and line is None

@@ -3,7 +3,10 @@
 // Plain C++ (g++) against cudavideostream_amd/compat: one diff::cuda::CUDACore runs a sequence of frames
 // through exec_core (the reference's call, server/src/server.cpp:139), a second one through
 // exec_submit / exec_wait with several frames in flight; h_pos, h_xs and the diff bytes of every frame
-// must be identical.  Exit status 0 = identical.
+// must be identical.  Exit status 0 = identical.  Also prints what the FIRST exec_core of a fresh core takes against the
+// median of the later ones (first_frame_ms / steady_frame_ms): nothing is allocated inside an entry point.
+#include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -45,10 +48,13 @@ int main(int argc, char **argv) {
     std::vector<unsigned int> want_pos(T);
     std::vector<std::vector<int>> want_xs(T);
     std::vector<std::vector<uint8_t>> want_df(T);
+    std::vector<double> ms(T);
     for (int t = 0; t < T; t++) {
         memcpy(f, frames[t].data(), n);
         unsigned int pos = 0;
+        const auto t0 = std::chrono::steady_clock::now();
         blocking.exec_core(f, nf, text, &pos, xs);
+        ms[t] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         want_pos[t] = pos;
         want_xs[t].assign(xs, xs + pos);
         want_df[t].assign(f, f + pos);
@@ -82,7 +88,10 @@ int main(int argc, char **argv) {
     piped.pipe_close();
     unsigned long total = 0;
     for (int t = 0; t < T; t++) total += want_pos[t];
-    printf("{\"compat_pipe\": \"%s\", \"frames\": %d, \"depth\": %d, \"changed_bytes\": %lu}\n", bad ? "MISMATCH" : "ok", T,
-           depth, total);
+    const double first_ms = ms[0];
+    std::vector<double> later(ms.begin() + (T > 1 ? 1 : 0), ms.end());
+    std::sort(later.begin(), later.end());
+    printf("{\"compat_pipe\": \"%s\", \"frames\": %d, \"depth\": %d, \"changed_bytes\": %lu, \"first_frame_ms\": %.3f, "
+           "\"steady_frame_ms\": %.3f}\n", bad ? "MISMATCH" : "ok", T, depth, total, first_ms, later[later.size() / 2]);
     return bad ? 1 : 0;
 }

@@ -15,6 +15,10 @@
 //             [--reroll N]              pairs: after the run, N new pairs of output arrays, N new index arrays, N new value
 //                                       arrays, N new cores, N new copies of the frames -- the kernels' times after each
 //                                       (which buffer's placement decides the dense expansion's speed: profiles/README.md)
+//             [--place N]               pairs: the two output arrays inside ONE allocation, the value array at a sweep of
+//                                       distances behind the index array and the pair at a sweep of displacements; then N
+//                                       pairs of arrays from hipMalloc, from the HIP virtual-memory calls (hipMemCreate: one
+//                                       physical handle per array) and from mi355_dev_alloc -- the expansion's time for each
 //   diffbench --filters [--batch B] [--steps K]     the filter kernels and the BASELINE config 3 / 4 chains
 //                                                   (same lines as tools/bench_filters.py, for the --pmc passes)
 #include <hip/hip_runtime.h>
@@ -98,7 +102,7 @@ int main(int argc, char **argv) {
     uint32_t seed = 21;
     bool pairs = false, filters = false, digest = false, apart = false, print_ptrs = false;
     size_t skew_xs = 0, skew_df = 0, skew_frames = 0;
-    int reroll = 0;
+    int reroll = 0, place = 0;
     const char *corun = nullptr; int corun_blocks = 2048;
     std::vector<std::pair<int, int>> opts;
     const char *regime = nullptr;   // --regime s0|flip|static: pairs of the dense / static regimes (tools/bench_regimes.py's inputs)
@@ -124,6 +128,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--skew-frames") && i + 1 < argc) skew_frames = (size_t)atoll(argv[++i]) & ~(size_t)15;
         else if (!strcmp(argv[i], "--print-ptrs")) print_ptrs = true;
         else if (!strcmp(argv[i], "--reroll")) next(reroll);
+        else if (!strcmp(argv[i], "--place")) next(place);
         else if (!strcmp(argv[i], "--opt") && i + 1 < argc) { int id = 0, v = 0; if (sscanf(argv[++i], "%d=%d", &id, &v) == 2) opts.push_back({id, v}); }
     }
     auto apply_opts = [&](mi355_core *c) { for (auto &o : opts) MI_OK(mi355_set_option(c, o.first, o.second)); };
@@ -374,6 +379,77 @@ int main(int argc, char **argv) {
             d_cur = copy + (d_cur - d_prev);
             d_prev = copy;
             measure("frames", i);
+        }
+    }
+    if (place > 0 && pairs) {
+        // Where do the two output arrays have to lie for the dense expansion to run at its fast speed (profiles/README.md, r06)?
+        auto measure = [&](const char *what, long long a, long long b2) {
+            for (int w = 0; w < WU; w++) MI_OK(mi355_diff_pairs_batch(core, d_cur, d_prev, apart ? 2 * n : n, B, d_off, d_xs, d_df, cap));
+            MI_OK(mi355_synchronize(core));
+            MI_OK(mi355_set_timing(core, 1));
+            MI_OK(mi355_reset_timing(core));
+            for (int k = 0; k < K; k++) MI_OK(mi355_diff_pairs_batch(core, d_cur, d_prev, apart ? 2 * n : n, B, d_off, d_xs, d_df, cap));
+            MI_OK(mi355_synchronize(core));
+            double ta = 0, tb = 0, tc = 0; int l = 0;
+            MI_OK(mi355_get_kernel_timing(core, &ta, &tb, &tc, &l));
+            printf("place %s %lld %lld: expand_us %.1f pack_us %.1f  xs %p df %p\n", what, a, b2, tc / l * 1e3, ta / l * 1e3, (void *)d_xs, (void *)d_df);
+            fflush(stdout);
+        };
+        const size_t xs_bytes = sizeof(int32_t) * cap, df_bytes = cap, MiB2 = (size_t)2 << 20;
+        const size_t xs_span = (xs_bytes + MiB2 - 1) / MiB2 * MiB2;
+        uint8_t *block = nullptr;
+        HIP_OK(hipMalloc((void **)&block, xs_span + df_bytes + 64 * MiB2));
+        printf("place block %p (%zu bytes): xs %zu bytes, df %zu bytes\n", (void *)block, xs_span + df_bytes + 64 * MiB2, xs_bytes, df_bytes);
+        const long long rel[] = {0, 256, 1024, 4096, 16384, 65536, 262144, 1 << 20, 2 << 20, (2 << 20) + 4096, 3 << 20, 4 << 20, 8 << 20, 16 << 20, 32 << 20};
+        for (int rep = 0; rep < 2; rep++)
+            for (long long r : rel) {
+                d_xs = (int32_t *)block; d_df = block + xs_span + r;
+                measure("rel", r, rep);
+            }
+        const long long dis[] = {0, 4096, 65536, 1 << 20, 2 << 20, 5 << 20, 16 << 20};
+        for (long long d : dis) {
+            d_xs = (int32_t *)(block + d); d_df = block + xs_span + (32 << 20) + d;
+            measure("both", d, 0);
+        }
+        // separate allocations, three ways
+        for (int i = 0; i < place; i++) {
+            HIP_OK(hipMalloc((void **)&d_xs, xs_bytes));
+            HIP_OK(hipMalloc((void **)&d_df, df_bytes));
+            measure("hipMalloc", i, 0);
+        }
+        auto vmm = [&](size_t bytes) -> void * {   // one physical handle, mapped at a reserved address range
+            hipMemAllocationProp prop{};
+            prop.type = hipMemAllocationTypePinned;
+            prop.location.type = hipMemLocationTypeDevice;
+            int dev = 0; HIP_OK(hipGetDevice(&dev));
+            prop.location.id = dev;
+            size_t gran = 0;
+            HIP_OK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+            const size_t sz = (bytes + gran - 1) / gran * gran;
+            hipMemGenericAllocationHandle_t h;
+            HIP_OK(hipMemCreate(&h, sz, &prop, 0));
+            void *va = nullptr;
+            HIP_OK(hipMemAddressReserve(&va, sz, gran, nullptr, 0));
+            HIP_OK(hipMemMap(va, sz, 0, h, 0));
+            hipMemAccessDesc acc{};
+            acc.location = prop.location;
+            acc.flags = hipMemAccessFlagsProtReadWrite;
+            HIP_OK(hipMemSetAccess(va, sz, &acc, 1));
+            static bool said = false;
+            if (!said) { printf("place vmm granularity %zu\n", gran); said = true; }
+            return va;
+        };
+        for (int i = 0; i < place; i++) {
+            d_xs = (int32_t *)vmm(xs_bytes);
+            d_df = (uint8_t *)vmm(df_bytes);
+            measure("vmm", i, 0);
+        }
+        for (int i = 0; i < place; i++) {
+            void *a = nullptr, *b3 = nullptr;
+            MI_OK(mi355_dev_alloc(core, &a, xs_bytes));
+            MI_OK(mi355_dev_alloc(core, &b3, df_bytes));
+            d_xs = (int32_t *)a; d_df = (uint8_t *)b3;
+            measure("mi355_dev_alloc", i, 0);
         }
     }
     mi355_destroy(core);
