@@ -60,6 +60,9 @@ CUDACore::CUDACore(uint8_t *charsPx, matsz &charsSz, float *k, int total, uint8_
         MI355_CHECK(mi355_set_glyphs(core_, charsPx, (int)(sizeof(CHARS_STR) - 1), charsSz.height,
                                      charsSz.width, CHARS_STR));
     if (sampleMatData) MI355_CHECK(mi355_set_state(core_, sampleMatData));        // kernels.cu:406
+    // nothing is left to be made, loaded or first-used inside exec_core (the reference allocates everything here too,
+    // kernels.cu:395-402)
+    MI355_CHECK(mi355_prepare(core_, MI355_PREPARE_EXEC | MI355_PREPARE_GRAY_CHAIN));
 }
 
 void CUDACore::exec_core(uint8_t *frameData, uint8_t *showReadyNData, std::string &text,

@@ -23,7 +23,7 @@ VIS_NONE, VIS_HEAT, VIS_RED, VIS_RED_OVERLAP, VIS_GRAY, VIS_BINARIZE = range(6)
 
 (OPT_PIPELINE, OPT_SPLIT_PCT, OPT_DENSE_PCT, OPT_CHAIN_HINT, OPT_PACK_BLOCKS, OPT_MEDIAN_ROWS,
  OPT_SCAN_EPOCH_LEFT) = range(1, 8)   # MI355_OPT_*
-PREPARE_BATCHES, PREPARE_GRAY_CHAIN, PREPARE_RED_CLEAR, PREPARE_CONV_KXK, PREPARE_ALL = 1, 2, 4, 8, 15   # MI355_PREPARE_*
+PREPARE_BATCHES, PREPARE_GRAY_CHAIN, PREPARE_RED_CLEAR, PREPARE_CONV_KXK, PREPARE_EXEC, PREPARE_ALL = 1, 2, 4, 8, 16, 31   # MI355_PREPARE_*
 
 
 class Config(C.Structure):
@@ -64,6 +64,8 @@ SYMBOLS = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi355_diff_stream_wire_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
                                                C.c_void_p, C.c_size_t]),
+    "mi355_diff_stream_binarize_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi355_wire_bytes": (C.c_size_t, [C.c_int, C.c_uint64]),
     "mi355_apply_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_size_t]),

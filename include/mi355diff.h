@@ -86,7 +86,12 @@ size_t mi355_workspace_bytes(const mi355_core *core);
  *                              (mi355_diff_stream_batch / _pairs_batch / _wire_batch on the core's own stream);
  *   MI355_PREPARE_GRAY_CHAIN   one gray byte per pixel for max_batch frames (MI355_OP_GRAY_*_BINARIZE, MI355_VIS_BINARIZE);
  *   MI355_PREPARE_RED_CLEAR    slice bounds of mi355_red_stream_batch(clear != 0);
- *   MI355_PREPARE_CONV_KXK     the tap buffer of mi355_conv_kxk.
+ *   MI355_PREPARE_CONV_KXK     the tap buffer of mi355_conv_kxk;
+ *   MI355_PREPARE_EXEC         one pass of mi355_exec's own kernels (noise filter if its kernel is set, visualiser, pack,
+ *                              index, expansion, red map, export) over a copy of the CURRENT state -- nothing differs, so
+ *                              the state and the caller's buffers stay as they are -- so that the first real frame does
+ *                              not pay for the first use of each kernel (measured: the first exec_core of a fresh core
+ *                              1.4 ms, the later ones 0.16).  The C++ drop-in's constructor calls it.
  * mi355_create already makes the one a per-frame server needs (MI355_VIS_BINARIZE's gray bytes).  Blocking; idempotent;
  * mi355_workspace_bytes grows by what was made.  After mi355_prepare(core, MI355_PREPARE_ALL) no entry point of the core
  * allocates (mi355_pipe_open and mi355_set_glyphs, which say so, excepted). */
@@ -94,7 +99,8 @@ size_t mi355_workspace_bytes(const mi355_core *core);
 #define MI355_PREPARE_GRAY_CHAIN 2u
 #define MI355_PREPARE_RED_CLEAR 4u
 #define MI355_PREPARE_CONV_KXK 8u
-#define MI355_PREPARE_ALL 15u
+#define MI355_PREPARE_EXEC 16u
+#define MI355_PREPARE_ALL 31u
 int mi355_prepare(mi355_core *core, unsigned what);
 
 /* Streams.  A core starts on a stream of its own, created hipStreamNonBlocking: it is NOT ordered against the
@@ -196,6 +202,15 @@ int mi355_diff_pairs_batch(mi355_core *core, const void *d_cur, const void *d_pr
                            size_t stride_bytes, int nframes, void *d_offsets, void *d_xs,
                            void *d_diff, size_t capacity);
 
+/* BASELINE configs[2] in ONE read of the colour frames (round 6): mi355_filter_batch(MI355_OP_GRAY_WEIGHTED_BINARIZE) followed
+ * by mi355_diff_stream_batch on the same frames -- the visualiser of kernels.cu:493-498 and kernel2 of :505 -- as one call in
+ * which the pack kernel also computes the weighted gray value of every pixel it passes (8 scratch bytes per 16 frame bytes,
+ * max_batch frames: made on first use or by MI355_PREPARE_GRAY_CHAIN), the histogram / two-max threshold / binarized frames
+ * follow from those: N instead of 2N bytes of colour frame read per frame.  d_vis: frame t's binarized BGR frame at d_vis +
+ * t * vis_stride_bytes.  Results identical to the two calls.  Runs on the core's stream, one kernel after the other (not
+ * overlapped with the next batch).  Frames that are not whole 16-byte aligned KiB tiles take the two calls internally. */
+int mi355_diff_stream_binarize_batch(mi355_core *core, const void *d_frames, size_t stride_bytes, int nframes, void *d_vis,
+                                     size_t vis_stride_bytes, void *d_offsets, void *d_xs, void *d_diff, size_t capacity);
 /* ---- the stream either side of the path ---------------------------------------
  * Wire form of mi355_diff_stream_batch: instead of separate (xs, diff) arrays the batch leaves as the exact
  * byte stream the reference's sender thread writes per frame (server/src/threads.cpp:227-229):

@@ -97,6 +97,63 @@ __global__ __launch_bounds__(64) void k_corun_mem(const uint4 *buf, size_t nvec,
     if (acc == 0x12345u) out[0] = acc;
 }
 
+// --place probes: what distinguishes output arrays on which the dense expansion is fast from those on which it is slow?
+typedef uint32_t pv4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_probe_wide(pv4 *buf, size_t nvec) {   // streaming 16-byte non-temporal stores
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const pv4 v = {(uint32_t)i, 1u, 2u, 3u};
+        __builtin_nontemporal_store(v, buf + i);
+    }
+}
+// the dense expansion's own shape: one wave per item, an item = a contiguous run of E entries: 16 bytes of indices and 4 of
+// values per lane and step, non-temporal
+__global__ __launch_bounds__(64) void k_probe_items(uint32_t *xs, uint8_t *df, uint32_t E, uint32_t items_per_frame) {
+    const size_t item = (size_t)blockIdx.y * items_per_frame + blockIdx.x;
+    uint32_t *x = xs + item * E;
+    uint8_t *d = df + item * E;
+    for (uint32_t e = threadIdx.x * 4u; e + 3u < E; e += 256u) {
+        const pv4 v = {e, e + 1u, e + 2u, e + 3u};
+        __builtin_nontemporal_store(v, reinterpret_cast<pv4 *>(x + e));
+        __builtin_nontemporal_store(e, reinterpret_cast<uint32_t *>(d + e));
+    }
+}
+// the same with the items dealt to the workgroups in a scattered order (item = w * step mod n): the waves that run at the same
+// time then write all over the arrays instead of inside one sliding window
+__global__ __launch_bounds__(64) void k_probe_items_perm(uint32_t *xs, uint8_t *df, uint32_t E, uint32_t nitems, uint32_t step) {
+    const size_t w = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (w >= nitems) return;
+    const size_t item = (w * step) % nitems;
+    uint32_t *x = xs + item * E;
+    uint8_t *d = df + item * E;
+    for (uint32_t e = threadIdx.x * 4u; e + 3u < E; e += 256u) {
+        const pv4 v = {e, e + 1u, e + 2u, e + 3u};
+        __builtin_nontemporal_store(v, reinterpret_cast<pv4 *>(x + e));
+        __builtin_nontemporal_store(e, reinterpret_cast<uint32_t *>(d + e));
+    }
+}
+// only the value array / only the index array of the expansion's shape
+__global__ __launch_bounds__(64) void k_probe_items_one(uint32_t *xs, uint8_t *df, uint32_t E, uint32_t items_per_frame, int which) {
+    const size_t item = (size_t)blockIdx.y * items_per_frame + blockIdx.x;
+    uint32_t *x = xs + item * E;
+    uint8_t *d = df + item * E;
+    for (uint32_t e = threadIdx.x * 4u; e + 3u < E; e += 256u) {
+        const pv4 v = {e, e + 1u, e + 2u, e + 3u};
+        if (which == 0) __builtin_nontemporal_store(v, reinterpret_cast<pv4 *>(x + e));
+        else __builtin_nontemporal_store(e, reinterpret_cast<uint32_t *>(d + e));
+    }
+}
+// one random 64-byte line per lane and step: address translation (TLB reach: page-fragment size) and row misses, no streaming
+__global__ __launch_bounds__(256) void k_probe_rand(const pv4 *buf, size_t nlines, uint32_t *sink, int iters) {
+    uint32_t x = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u, acc = 0;
+    for (int i = 0; i < iters; i++) {
+        x = x * 1664525u + 1013904223u;
+        const size_t line = ((size_t)x * 2654435761ull >> 7) % nlines;
+        acc += buf[line * 4].x;
+    }
+    if (acc == 0x12345u) sink[0] = acc;
+}
+
 int main(int argc, char **argv) {
     int W = 1920, H = 1080, B = 256, K = 20, WU = 3, checksum_t = -2, ncores = 1;
     uint32_t seed = 21;
@@ -401,55 +458,115 @@ int main(int argc, char **argv) {
         HIP_OK(hipMalloc((void **)&block, xs_span + df_bytes + 64 * MiB2));
         printf("place block %p (%zu bytes): xs %zu bytes, df %zu bytes\n", (void *)block, xs_span + df_bytes + 64 * MiB2, xs_bytes, df_bytes);
         const long long rel[] = {0, 256, 1024, 4096, 16384, 65536, 262144, 1 << 20, 2 << 20, (2 << 20) + 4096, 3 << 20, 4 << 20, 8 << 20, 16 << 20, 32 << 20};
-        for (int rep = 0; rep < 2; rep++)
+        const bool sweeps = !getenv("DIFFBENCH_PLACE_NO_SWEEPS");
+        for (int rep = 0; rep < 2 && sweeps; rep++)
             for (long long r : rel) {
                 d_xs = (int32_t *)block; d_df = block + xs_span + r;
                 measure("rel", r, rep);
             }
         const long long dis[] = {0, 4096, 65536, 1 << 20, 2 << 20, 5 << 20, 16 << 20};
         for (long long d : dis) {
+            if (!sweeps) break;
             d_xs = (int32_t *)(block + d); d_df = block + xs_span + (32 << 20) + d;
             measure("both", d, 0);
         }
-        // separate allocations, three ways
+        // separate allocations, kept allocated: the expansion on each pair, then three probes on the same memory
+        hipEvent_t pe0, pe1; HIP_OK(hipEventCreate(&pe0)); HIP_OK(hipEventCreate(&pe1));
+        uint32_t *psink; HIP_OK(hipMalloc((void **)&psink, 64));
+        auto timed_us = [&](auto fn) {
+            float best = 1e30f;
+            for (int r = 0; r < 4; r++) {
+                HIP_OK(hipEventRecord(pe0, 0)); fn(); HIP_OK(hipEventRecord(pe1, 0)); HIP_OK(hipEventSynchronize(pe1));
+                float ms = 0; HIP_OK(hipEventElapsedTime(&ms, pe0, pe1));
+                if (r > 0 && ms < best) best = ms;
+            }
+            return best * 1e3;
+        };
+        const uint32_t items = (uint32_t)((n / 1024 + 15) / 16), E = (uint32_t)(cap / ((size_t)items * B)) & ~3u;
+        auto probes = [&](const char *what, int i) {
+            MI_OK(mi355_synchronize(core));
+            const double wide_xs = timed_us([&] { hipLaunchKernelGGL(k_probe_wide, dim3(2048), dim3(256), 0, 0, (pv4 *)d_xs, xs_bytes / 16); });
+            const double wide_df = timed_us([&] { hipLaunchKernelGGL(k_probe_wide, dim3(2048), dim3(256), 0, 0, (pv4 *)d_df, df_bytes / 16); });
+            const double it = timed_us([&] { hipLaunchKernelGGL(k_probe_items, dim3(items, B), dim3(64), 0, 0, (uint32_t *)d_xs, d_df, E, items); });
+            const double itp = timed_us([&] { hipLaunchKernelGGL(k_probe_items_perm, dim3(items, B), dim3(64), 0, 0, (uint32_t *)d_xs, d_df, E, items * B, 4099u); });
+            const double only_x = timed_us([&] { hipLaunchKernelGGL(k_probe_items_one, dim3(items, B), dim3(64), 0, 0, (uint32_t *)d_xs, d_df, E, items, 0); });
+            const double only_d = timed_us([&] { hipLaunchKernelGGL(k_probe_items_one, dim3(items, B), dim3(64), 0, 0, (uint32_t *)d_xs, d_df, E, items, 1); });
+            printf("probe2 %s %d: items_perm %.1f us  items_xs_only %.1f us  items_df_only %.1f us\n", what, i, itp, only_x, only_d);
+            const double rx = timed_us([&] { hipLaunchKernelGGL(k_probe_rand, dim3(2048), dim3(256), 0, 0, (const pv4 *)d_xs, xs_bytes / 64, psink, 64); });
+            const double rd = timed_us([&] { hipLaunchKernelGGL(k_probe_rand, dim3(2048), dim3(256), 0, 0, (const pv4 *)d_df, df_bytes / 64, psink, 64); });
+            printf("probe %s %d: wide_xs %.1f us (%.0f GB/s) wide_df %.1f us (%.0f GB/s) items %.1f us (%.0f GB/s) rand_xs %.1f us rand_df %.1f us\n", what, i,
+                   wide_xs, xs_bytes / wide_xs / 1e3, wide_df, df_bytes / wide_df / 1e3, it, 5.0 * E * items * B / it / 1e3, rx, rd);
+            fflush(stdout);
+        };
+        const int burn_gb = getenv("DIFFBENCH_BURN_GB") ? atoi(getenv("DIFFBENCH_BURN_GB")) : 0;
+        for (int g2 = 0; g2 < burn_gb; g2++) { void *b4 = nullptr; HIP_OK(hipMalloc(&b4, (size_t)1 << 30)); }
+        if (burn_gb) printf("place burned %d GiB\n", burn_gb);
+        std::vector<std::pair<int32_t *, uint8_t *>> kept;
         for (int i = 0; i < place; i++) {
             HIP_OK(hipMalloc((void **)&d_xs, xs_bytes));
             HIP_OK(hipMalloc((void **)&d_df, df_bytes));
+            kept.push_back({d_xs, d_df});
             measure("hipMalloc", i, 0);
+            probes("hipMalloc", i);
         }
-        auto vmm = [&](size_t bytes) -> void * {   // one physical handle, mapped at a reserved address range
+        // the same arrays again in reverse order: is the speed a property of the MEMORY (it stays with the array)?
+        for (int i = place - 1; i >= 0; i -= 3) { d_xs = kept[i].first; d_df = kept[i].second; measure("again", i, 0); }
+        // mixed: index array of the last pair (the latest draw) with the value array of the first, and the other way round
+        if (place > 1) {
+            d_xs = kept[place - 1].first; d_df = kept[0].second; measure("mixed_xs_last_df_first", 0, 0);
+            d_xs = kept[0].first; d_df = kept[place - 1].second; measure("mixed_xs_first_df_last", 0, 0);
+        }
+        // free everything and draw again: does a fresh draw get the same memory back?
+        for (auto &kv : kept) { HIP_OK(hipFree(kv.first)); HIP_OK(hipFree(kv.second)); }
+        for (int i = 0; i < 3; i++) {
+            HIP_OK(hipMalloc((void **)&d_xs, xs_bytes));
+            HIP_OK(hipMalloc((void **)&d_df, df_bytes));
+            measure("after_free", i, 0);
+        }
+        // the value array put together from separately made physical pieces (HIP virtual-memory calls), mapped one after the
+        // other or in a shuffled order: is scattered memory the fast kind?
+        auto vmm_pieces = [&](size_t bytes, size_t piece, bool shuffle) -> void * {
             hipMemAllocationProp prop{};
             prop.type = hipMemAllocationTypePinned;
             prop.location.type = hipMemLocationTypeDevice;
             int dev = 0; HIP_OK(hipGetDevice(&dev));
             prop.location.id = dev;
-            size_t gran = 0;
-            HIP_OK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
-            const size_t sz = (bytes + gran - 1) / gran * gran;
-            hipMemGenericAllocationHandle_t h;
-            HIP_OK(hipMemCreate(&h, sz, &prop, 0));
+            const size_t np = (bytes + piece - 1) / piece;
             void *va = nullptr;
-            HIP_OK(hipMemAddressReserve(&va, sz, gran, nullptr, 0));
-            HIP_OK(hipMemMap(va, sz, 0, h, 0));
+            HIP_OK(hipMemAddressReserve(&va, np * piece, (size_t)2 << 20, nullptr, 0));
+            std::vector<hipMemGenericAllocationHandle_t> hs(np);
+            for (size_t k = 0; k < np; k++) HIP_OK(hipMemCreate(&hs[k], piece, &prop, 0));
+            std::vector<size_t> order(np);
+            for (size_t k = 0; k < np; k++) order[k] = k;
+            if (shuffle) { uint32_t r = 12345u; for (size_t k = np - 1; k > 0; k--) { r = r * 1664525u + 1013904223u; std::swap(order[k], order[(r >> 8) % (k + 1)]); } }
+            for (size_t k = 0; k < np; k++) HIP_OK(hipMemMap((char *)va + k * piece, piece, 0, hs[order[k]], 0));
             hipMemAccessDesc acc{};
             acc.location = prop.location;
             acc.flags = hipMemAccessFlagsProtReadWrite;
-            HIP_OK(hipMemSetAccess(va, sz, &acc, 1));
-            static bool said = false;
-            if (!said) { printf("place vmm granularity %zu\n", gran); said = true; }
+            HIP_OK(hipMemSetAccess(va, np * piece, &acc, 1));
             return va;
         };
-        for (int i = 0; i < place; i++) {
-            d_xs = (int32_t *)vmm(xs_bytes);
-            d_df = (uint8_t *)vmm(df_bytes);
-            measure("vmm", i, 0);
-        }
-        for (int i = 0; i < place; i++) {
+        HIP_OK(hipMalloc((void **)&d_xs, xs_bytes));
+        const size_t pieces[] = {(size_t)2 << 20, (size_t)256 << 10, (size_t)64 << 10};
+        for (size_t pc : pieces)
+            for (int sh = 0; sh < 2; sh++)
+                for (int i = 0; i < 2; i++) {
+                    const auto t0p = std::chrono::high_resolution_clock::now();
+                    d_df = (uint8_t *)vmm_pieces(df_bytes, pc, sh != 0);
+                    const double ms_make = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0p).count() * 1e3;
+                    char name[64]; snprintf(name, sizeof name, "vmm_%zuK_%s", pc >> 10, sh ? "shuffled" : "inorder");
+                    printf("place %s made in %.1f ms\n", name, ms_make);
+                    measure(name, i, 0);
+                    probes(name, i);
+                }
+        for (int i = 0; i < 3; i++) {   // physically contiguous allocations
             void *a = nullptr, *b3 = nullptr;
-            MI_OK(mi355_dev_alloc(core, &a, xs_bytes));
-            MI_OK(mi355_dev_alloc(core, &b3, df_bytes));
+            if (hipExtMallocWithFlags(&a, xs_bytes, hipDeviceMallocContiguous) != hipSuccess || hipExtMallocWithFlags(&b3, df_bytes, hipDeviceMallocContiguous) != hipSuccess) {
+                printf("place contiguous: refused (%s)\n", hipGetErrorString(hipGetLastError())); break;
+            }
             d_xs = (int32_t *)a; d_df = (uint8_t *)b3;
-            measure("mi355_dev_alloc", i, 0);
+            measure("contiguous", i, 0);
+            probes("contiguous", i);
         }
     }
     mi355_destroy(core);
