@@ -1260,26 +1260,42 @@ def config5_across_ranks(args, dist, world, rank, local_rank, dev, cdev, rehears
 def regimes(args, dev, B=32):
     """Secondary lines: the same path on the other input regimes of SURVEY.md 8d, 32-frame batches, whole-path
     fractions: S0 refrand pairs (the generator of tests/algorithms_benchmarks.cu:4-10, P ~ 0.85 N), every byte
-    changed (P = N), nothing changed (P = 0)."""
+    changed (P = N), nothing changed (P = 0).  The two output arrays come from mi355_alloc_outputs: in the dense regimes
+    the expansion is bound by its stores, and whether the index and the value stream overlap in the memory system is a
+    property of the pair's placement (205 or 265 us per 32 S0 pairs: include/mi355diff.h); `plain_allocation` repeats the
+    S0 line on two torch.empty arrays -- whatever lot this process draws."""
     W, H = args.width, args.height
     n = 3 * W * H
     cap = B * n
     d_off = torch.zeros(B + 1, dtype=torch.int32, device=dev)
-    d_xs = torch.empty(cap, dtype=torch.int32, device=dev)
-    d_df = torch.empty(cap, dtype=torch.uint8, device=dev)
     rnd = torch.stack([synth.refrand_frame(n, 100 + t, device=dev) for t in range(2 * B)])
     flip = rnd[:B] ^ 0x80
     out = {}
     with CUDACore(W, H, max_batch=B) as core:
+        t0 = time.perf_counter()
+        d_xs, d_df, draws = core.alloc_outputs(cap)
+        alloc_ms = (time.perf_counter() - t0) * 1e3
         core.use_torch_stream()
-        for name, cur, prev in (("S0_refrand_pairs", rnd[B:], rnd[:B]), ("P_eq_N_pairs", flip, rnd[:B]),
-                                ("P_eq_0_pairs", rnd[:B], rnd[:B].clone())):
-            sec, ms, launches = timed_path(core, lambda: core.diff_pairs_batch(cur, prev, B, d_off, d_xs, d_df, cap), 10, 2)
+
+        def line(cur, prev, xs, df):
+            sec, ms, launches = timed_path(core, lambda: core.diff_pairs_batch(cur, prev, B, d_off, xs, df, cap), 10, 2)
             core.use_own_stream()
-            sec_pipe = wall_per_call(core, lambda: core.diff_pairs_batch(cur, prev, B, d_off, d_xs, d_df, cap), 10, 2)
+            sec_pipe = wall_per_call(core, lambda: core.diff_pairs_batch(cur, prev, B, d_off, xs, df, cap), 10, 2)
             core.use_torch_stream()
             p = int(d_off.cpu().numpy().view(np.uint32)[B])
-            out[name] = path_line(B, n, p, sec, ms, launches, True, sec_pipe)
+            return path_line(B, n, p, sec, ms, launches, True, sec_pipe)
+
+        for name, cur, prev in (("S0_refrand_pairs", rnd[B:], rnd[:B]), ("P_eq_N_pairs", flip, rnd[:B]),
+                                ("P_eq_0_pairs", rnd[:B], rnd[:B].clone())):
+            out[name] = line(cur, prev, d_xs, d_df)
+        out["outputs"] = {"from": "mi355_alloc_outputs", "value_arrays_drawn": draws, "ms": round(alloc_ms, 1)}
+        t_xs = torch.empty(cap, dtype=torch.int32, device=dev)
+        t_df = torch.empty(cap, dtype=torch.uint8, device=dev)
+        plain = line(rnd[B:], rnd[:B], t_xs, t_df)
+        out["S0_refrand_pairs"]["plain_allocation"] = {k: plain[k] for k in ("frac", "frac_sequential", "kernels_us")}
+        core.synchronize()
+        core.dev_free(d_xs)
+        core.dev_free(d_df)
     return out
 
 

@@ -119,6 +119,16 @@ class CUDACore:
         asynchronous call allocates."""
         _l.check(self._lib.mi355_prepare(self._h, int(what)))
 
+    def alloc_outputs(self, capacity):
+        """mi355_alloc_outputs: (d_xs, d_diff, draws) -- device addresses (ints) of an index array and a value array of
+        `capacity` entries whose placement lets the dense expansion run at its fast speed; free with dev_free()."""
+        xs, df, draws = C.c_void_p(), C.c_void_p(), C.c_int(0)
+        _l.check(self._lib.mi355_alloc_outputs(self._h, int(capacity), C.byref(xs), C.byref(df), C.byref(draws)))
+        return int(xs.value), int(df.value), draws.value
+
+    def dev_free(self, d_ptr):
+        _l.check(self._lib.mi355_dev_free(self._h, C.c_void_p(int(d_ptr))))
+
     def use_torch_stream(self):
         """Enqueue on PyTorch's current stream (0 = the default stream), so torch ops, events and
         collectives issued on it are ordered with the core's kernels."""

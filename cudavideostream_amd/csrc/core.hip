@@ -105,7 +105,7 @@ struct mi355_core {
         hipEvent_t packed = nullptr, expanded = nullptr;   // pack kernel done (main) / expansion done (side)
         bool in_use = false;                                // `expanded` has been recorded at least once
     };
-    static constexpr int kSets = 2;   // (a third set was measured: no gain, profiles/r04ay)
+    static constexpr int kSets = 2;   // (a third set was measured: no gain, profiles/archive/r04ay)
     LogSet set[kSets];
     int flip = 0;
     hipStream_t side = nullptr;
@@ -114,10 +114,11 @@ struct mi355_core {
     int pack_blocks_opt = -1;         // MI355_OPT_PACK_BLOCKS (-1: the default, 4 workgroups per CU)
     int median_rows = 0;              // MI355_OPT_MEDIAN_ROWS (0: chosen per launch)
     uint32_t k1_blocks = 0;           // pipelined batches: workgroups of the pack kernel (0 = one tile per wave)
+    uint32_t cu_count = 0;            // compute units of the device
     // pipelined batches packed by TWO launches (tiles [0, split) on the core's stream, the rest on `main2`): the two chains
     // of pack kernels drift apart, each one's kernel boundary (L2 write-back, event packets: 21-25 us) falls into the other's
     // kernel.  split_pct = 0: one launch.
-    // (three or four launches were measured: much slower, profiles/r04ah)
+    // (three or four launches were measured: much slower, profiles/archive/r04ah)
     int split_pct = 50;               // MI355_OPT_SPLIT_PCT
     hipStream_t main2 = nullptr;
     hipEvent_t packed2[kSets] = {};
@@ -191,7 +192,7 @@ int use_device(mi355_core *c, bool join = true, bool parts = true) {
 // side stream.  It leaves a hint, though: a caller that alternates filters and batches (the server's visualiser or noise
 // filter in front of every diff: BASELINE configs 3 and 4) gains nothing from a batch's expansion running beside the next
 // filter -- both are bound by the memory system -- and loses the pipelined batch's smaller pack grid and stream hops:
-// 4.6 us per frame one after the other, 5.0-5.2 overlapped (config 3, profiles/r04bd).  The next batch therefore runs one
+// 4.6 us per frame one after the other, 5.0-5.2 overlapped (config 3, profiles/archive/r04bd).  The next batch therefore runs one
 // kernel after the other on the core's stream (MI355_OPT_CHAIN_HINT 0: ignore the hint).
 int use_device_filter(mi355_core *c) {
     c->filter_since_batch = c->chain_hint;
@@ -266,7 +267,7 @@ int setup_pipeline(mi355_core *c) {
     // one tile per wave (6 per CU).  It is bound by the memory system and does not need its occupancy (profiles/README.md,
     // round 1), while the expansion of the batch before, which shares the chip with it, lives on the wave slots and
     // registers that are left: 0.503-0.507 -> 0.487-0.497 ms per batch on the faster boxes, +-1 % on the slower ones
-    // (profiles/r04p, r04q, r04v).  MI355_OPT_PACK_BLOCKS overrides (0 = one tile per wave).
+    // (profiles/archive/r04p, r04q, r04v).  MI355_OPT_PACK_BLOCKS overrides (0 = one tile per wave).
     if (c->pack_blocks_opt >= 0) {
         c->k1_blocks = (uint32_t)c->pack_blocks_opt;
     } else {
@@ -435,14 +436,17 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
         if (tev) HIP_TRY(hipEventRecord(tev[5], c->main2));   // the pack "kernel" of a split batch ends when BOTH parts have
         c->parts_pending = c->flip;
     } else {
-        HIP_TRY(launch_diff_pack(a, pair, aligned, pair_once, pipelined ? c->k1_blocks : 0u, c->stream));
+        // (the one-read config 3 form of the kernel holds 87 registers -- five waves per SIMD, not the six a 1080p frame's tiles
+        // need at one tile per wave --: four workgroups per CU walk the tiles, like the pipelined pack kernel)
+        const uint32_t gray_blocks = c->pack_blocks_opt >= 0 ? (uint32_t)c->pack_blocks_opt : 4u * c->cu_count;
+        HIP_TRY(launch_diff_pack(a, pair, aligned, pair_once, pipelined ? c->k1_blocks : (want_gray8 ? gray_blocks : 0u), c->stream));
     }
     if (tev) {
         HIP_TRY(hipEventRecord(tev[1], c->stream));
         c->ev_split[(c->ev_head + c->ev_count) % mi355_core::kEvRing] = split;
     }
     // The index kernel is short (12 us alone) and gates the expansion; it runs in front of it on the side stream (on the
-    // core's stream, between two pack kernels, was measured: worse, profiles/r04a).
+    // core's stream, between two pack kernels, was measured: worse, profiles/archive/r04a).
     if (pipelined) {
         HIP_TRY(hipEventRecord(ls.packed, c->stream));
         HIP_TRY(hipStreamWaitEvent(tail, ls.packed, 0));
@@ -536,6 +540,10 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
 
     c->n = (uint32_t)n64;
     c->ntiles = (c->n + kTileBytes - 1) / kTileBytes;
+    {
+        hipDeviceProp_t prop{};
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->cu_count = (uint32_t)prop.multiProcessorCount;
+    }
     const size_t T = (size_t)cfg->max_batch, W = c->ntiles, N = c->n;
 
     int rc = use_device(c);

@@ -216,12 +216,12 @@ struct Group {
     // Aligned tiles (round 4): the group's frames through ONE buffer descriptor that starts at the group's first frame
     // and ends with the batch; voff[d] = the lane's byte offset + d * stride.  A frame costs no address arithmetic at
     // all (round 3: 8 scalar instructions to clamp the frame pointer to the last frame + a 64-bit vector add per load;
-    // scalar instructions are not free on this chip: ~2.6 cycles of the SIMD's issue time each, profiles/r04n), and
+    // scalar instructions are not free on this chip: ~2.6 cycles of the SIMD's issue time each, profiles/archive/r04n), and
     // frames beyond the batch are out of the descriptor's range: they return zeros and read nothing.
     // ONCE: every frame is read once by this batch -- the frames of a stream, or pairs whose operands share no frame
     // (round-robin shards: pairs (f - 1, f) of every 8th f): non-temporal loads, +7 % for such pairs (0.355 -> 0.332 ms per
     // 128 pairs of 1080p, 4K 0.60 -> 0.63 of the roofline); pairs of CONSECUTIVE frames, where cur of one pair is prev of
-    // the next, keep the plain policy (the second read hits): non-temporal loads cost them 6 % (profiles/r04av).
+    // the next, keep the plain policy (the second read hits): non-temporal loads cost them 6 % (profiles/archive/r04av).
     template <bool ONCE, bool GRAY = false>
     __device__ __forceinline__ void load_desc(__amdgpu_buffer_rsrc_t cur, __amdgpu_buffer_rsrc_t prev, const uint32_t (&voff)[kPrefetch],
                                               const uint32_t (&nxv)[kPrefetch]) {
@@ -318,7 +318,7 @@ template <bool PAIR, bool FAST, bool HIGH, bool ONCE, bool GRAY = false>
 __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint32_t byte_off,
                                           int valid, int lane) {
     const int T = a.nframes;
-    // the compare constants stay in scalar registers: in vector registers the kernel was 4 % slower (profiles/r04o)
+    // the compare constants stay in scalar registers: in vector registers the kernel was 4 % slower (profiles/archive/r04o)
     const ThrConst tc = make_thr((uint32_t)a.thr);
     const LogOut lg{make_rsrc(a.codes, a.codes_bytes), make_rsrc(a.rec, a.rec_bytes), make_rsrc(a.meta, a.meta_bytes)};
 
@@ -608,7 +608,7 @@ hipError_t launch_scan(const uint4 *meta, uint32_t *roff, uint64_t *totals, uint
 //     its 1024 bytes flagged bypasses the stage: its 64 records ARE the difference bytes, the indices are consecutive.
 // Round 3's expander packed the candidates of all 16 tiles densely into rounds of 64 and needed a table, a
 // running-maximum scan and a second table per round to find a candidate's tile again (~1150 instructions per item of
-// the 1080p stream, 0.144 ms per batch; the kernel is bound by what its waves issue -- profiles/r04c, r04f).
+// the 1080p stream, 0.144 ms per batch; the kernel is bound by what its waves issue -- profiles/archive/r04c, r04f).
 // No barriers; 5 KB of LDS and at most 64 VGPRs: 32 waves per CU, the kernel lives on its occupancy.
 //
 // WIRE: the entries leave in the sender's byte stream instead (server/src/threads.cpp:227-229): frame t
@@ -630,7 +630,7 @@ __device__ __forceinline__ void lds_handoff() {
 // wire, the differences start at any byte).
 // The packed stream is written once and not read again by this library's path: its stores are NON-TEMPORAL (round 4), so
 // that they do not push the logs -- written by the pack kernel, read back here one batch later -- out of the caches.
-// Measured (profiles/r04an, r04ao): the batch 4-5 % faster on the slower boards of the pool (0.502 -> 0.479 ms) and
+// Measured (profiles/archive/r04an, r04ao): the batch 4-5 % faster on the slower boards of the pool (0.502 -> 0.479 ms) and
 // sequentially (0.537 -> 0.514), unchanged on the fastest.  (Round 1 measured the opposite for its 4-byte + 1-byte
 // scattered stores, r01d: a non-temporal store wants whole 16-byte pieces.)  The log itself is read with plain loads
 // (non-temporal ones: no gain, profiles/README.md r04).
@@ -682,7 +682,7 @@ __device__ __forceinline__ void flush_entries(const ExpandArgs &a, const uint32_
 
 // The expander declares 64 vector registers although it uses 50: beside the pack kernel of the next batch (4 waves of 72
 // registers per SIMD) three of its waves fit instead of four, and the pair is 1 % faster that way (0.539 against 0.546 ms
-// per batch, profiles/r04z: the more the expansion crowds the pack kernel, the more the pack kernel -- the longer of
+// per batch, profiles/archive/r04z: the more the expansion crowds the pack kernel, the more the pack kernel -- the longer of
 // the two -- stretches).  Alone the kernel runs 8 waves per SIMD either way.
 constexpr uint32_t kWTiles = 16;             // tiles per item: one DPP row of lanes, a quarter of a scan group
 constexpr uint32_t kWStage = 1024;           // entries of the LDS stage = the most one tile can hold
@@ -768,7 +768,7 @@ __device__ __forceinline__ void walk_records(uint32_t m16, uint32_t e, uint32_t 
 // (G = 4: "quads", G = 2: "pairs"), whose candidates together fill at most the 64 lanes: those of the first tile in lanes
 // 0 .. nc0 - 1, those of the next behind them, and so on.  What a round needs of its tiles is wave-uniform and is read into
 // SGPRs (v_readlane) right where it is used: through LDS the same facts cost a write, a read and a wait per round (~150
-// cycles each; a third of the wave's lifetime, profiles/r04l_expand_stamps.log).  Which tile of the group a candidate
+// cycles each; a third of the wave's lifetime, profiles/archive/r04l_expand_stamps.log).  Which tile of the group a candidate
 // belongs to is written in its code (bits 30..31 = tile & 3, k_diff_pack): only the LOAD of the codes has to find a lane's
 // tile from the counts (G - 1 compares).  A candidate's place in the output needs no tile at all: the tiles of a group
 // are neighbours in the output too, so it is the entries in front of the group plus the wave-wide scan of the round.
@@ -1027,7 +1027,7 @@ hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s) {
     // land on the same XCD for every frame (the padding workgroups return at once).  It matters: a 128-byte line of a
     // tile's code log holds the codes of two consecutive frames, a line of its record log those of two or three, and the
     // L2s of the XCDs do not share -- without the padding the expander's requests to memory rise by 78 % (TCC_EA0_RDREQ
-    // 1.87 M -> 3.33 M per batch, L2 hit rate 55 % -> 38 %, profiles/r04_tcc_grid_padding.txt).
+    // 1.87 M -> 3.33 M per batch, L2 hit rate 55 % -> 38 %, profiles/archive/r04_tcc_grid_padding.txt).
     const uint32_t gx = ((a.ntiles + kWTiles - 1) / kWTiles + kXWaves - 1) / kXWaves;   // workgroups per frame
     const dim3 grid((gx + 7u) / 8u * 8u, nframes);
     if (a.wire)

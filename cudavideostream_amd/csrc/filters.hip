@@ -36,7 +36,7 @@ __device__ __forceinline__ Px16 load_px16(const uint8_t *p, int nbytes) {
 }
 
 // The colour frames of the filters are read with plain loads: non-temporal ones were measured 10 % SLOWER (gray 2.07 ->
-// 2.37 us per frame, profiles/r04au): a 128-byte line is touched by three of these loads, 16 bytes per lane at a 48-byte
+// 2.37 us per frame, profiles/archive/r04au): a 128-byte line is touched by three of these loads, 16 bytes per lane at a 48-byte
 // stride, and a non-temporal line does not wait in the cache for the other two.
 __device__ __forceinline__ Px16 load_px16_once(const uint8_t *p) { return load_px16<true>(p, 48); }
 
@@ -63,7 +63,7 @@ __device__ __forceinline__ void store_px16(uint8_t *p, const Px16 &r, int nbytes
 // ... and they are NON-TEMPORAL stores (round 4): a visualiser frame is written once and read by nobody on this path; kept
 // out of the caches it leaves them to the frames and logs of the diff that follows (fused gray+binarize 2.90 -> 2.74 us per
 // 1080p frame, config 3's chain 4.9 -> 4.75-4.85; the noise filter's output, which the diff reads next, gains nothing:
-// profiles/r04at_filters_nt_stores.log).
+// profiles/archive/r04at_filters_nt_stores.log).
 __device__ __forceinline__ void store_px16_wave(uint8_t *wave_base, const Px16 &r, uint4 *lds /* 192 per wave */) {
     const uint32_t lane = threadIdx.x & 63u;
     lds[lane * 3u + 0u] = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
@@ -82,7 +82,7 @@ __device__ __forceinline__ void store_px16_wave(uint8_t *wave_base, const Px16 &
 
 // (The same regrouping on the LOAD side -- three wave-contiguous 1 KiB loads, the lanes' 48-byte pieces read back from
 // LDS -- was measured and is not done: no gain for gray / binarize / red, the heat map slower (its LUT also lives in LDS):
-// the caches already serve the strided loads, profiles/r03t_filters_lds_ab.log.)
+// the caches already serve the strided loads, profiles/archive/r03t_filters_lds_ab.log.)
 __device__ __forceinline__ Px16 load_px16_full(const uint8_t *in, size_t off) { return load_px16<true>(in + off, 48); }
 
 // A lane's 48 bytes at out + off, through the wave-contiguous form when every lane of the wave stores a full piece.
@@ -155,7 +155,7 @@ hipError_t launch_int_diff(const int32_t *cur, const int32_t *prev, int32_t *out
 // tests/test_filters_gpu.py::test_gray_weighted_exhaustive_2_24 (device).
 __device__ uint16_t g_gray_exc[65536];
 
-// Measured (profiles/r03w_gray_integer_ab.log): no faster -- the gray kernels run at the memory system's rate either
+// Measured (profiles/archive/r03w_gray_integer_ab.log): no faster -- the gray kernels run at the memory system's rate either
 // way (2.15 us per 1080p frame), and the histogram pass of the fused chain is 4 % SLOWER in integers (3.37 against
 // 3.25 us for the chain): the rare table look-up is a dependent L2 access in the middle of a streaming kernel.
 // The product therefore keeps the fp64 form; -DMI355_GRAY_FP64=0 builds the integer one (bit-exact: the exhaustive
@@ -938,7 +938,7 @@ __device__ __forceinline__ float byte_f(uint32_t dw, int b) {  // b is a compile
 //   * rows are requested THREE rows ahead (a ring of three rows in flight, 15 registers);
 //   * a row is ONE 16-byte load per lane: the three bytes either side come from the neighbour lanes' registers
 //     (DPP wave_shr:1 / wave_shl:1 of the dword next to the seam) instead of two more dword loads per lane through
-//     the cache (1.34 x the frame's bytes fetched, profiles/r04_filters_pmc.json); only lanes 0 and 63 fetch the
+//     the cache (1.34 x the frame's bytes fetched, profiles/archive/r04_filters_pmc.json); only lanes 0 and 63 fetch the
 //     dword beyond the wave's 1 KiB (one load instruction, every other lane's offset is out of range and reads nothing);
 //   * loads and stores go through buffer descriptors: rows outside the image are a descriptor of zero records (the
 //     hardware returns zeros: kernels.cu:111-115), lanes beyond the row end carry an out-of-range offset -- no address

@@ -62,7 +62,7 @@ __host__ __device__ inline ThrConst make_thr(uint32_t thr /* 0..255 */) {
 }
 
 // A wave-uniform constant as a VECTOR register.  On gfx950 a VALU instruction with a scalar-register operand issues in
-// ~4.4 cycles per wave64 against ~2.7 for the all-vector form (tools/ubench/issue_rate2.hip, profiles/r04n): the pack
+// ~4.4 cycles per wave64 against ~2.7 for the all-vector form (tools/ubench/issue_rate2.hip, profiles/archive/r04n): the pack
 // kernel uses its three compare constants 16 times per KiB-step.  The asm keeps the compiler from folding the value back
 // into an SGPR or a literal.
 __device__ __forceinline__ uint32_t vgpr_const(uint32_t v) {

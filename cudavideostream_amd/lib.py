@@ -95,6 +95,7 @@ SYMBOLS = {
     "mi355_host_free": (C.c_int, [C.c_void_p]),
     "mi355_dev_alloc": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
     "mi355_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi355_alloc_outputs": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "mi355_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi355_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi355_set_timing": (C.c_int, [C.c_void_p, C.c_int]),

@@ -344,6 +344,16 @@ int mi355_host_free(void *p);
  * (mi355_upload returns once the host buffer may be reused, mi355_download once the bytes are there). */
 int mi355_dev_alloc(mi355_core *core, void **out, size_t bytes);
 int mi355_dev_free(mi355_core *core, void *d_ptr);
+/* The two output arrays of the batch entry points -- d_xs (capacity x int32) and d_diff (capacity x uint8) -- as a PAIR whose
+ * placement in memory lets the DENSE expansion run at its fast speed.  When most bytes of a frame change (a scene cut, the
+ * synthetic worst cases S0 / P = N), the expansion is bound by its stores to these two arrays, and their two streams either
+ * overlap in the memory system (205 us per 32 dense 1080p frames) or do not (265): a property of the pair's physical memory
+ * that no address shows, the same for the life of the arrays; about one pair in six of plain allocations is the fast kind
+ * (round 6, profiles/README.md).  This call allocates the index array, then draws value arrays (at most 32, each probed for
+ * ~2 ms with the expansion's own store shape) until the pair is of the fast kind, frees the others and returns the pair;
+ * *draws (may be NULL) = value arrays drawn.  Arrays below a few hundred MB of capacity, and sparse streams (a webcam's:
+ * the expansion is then bound elsewhere), need none of this: plain allocations.  Free both with mi355_dev_free. */
+int mi355_alloc_outputs(mi355_core *core, size_t capacity, void **d_xs, void **d_diff, int *draws);
 int mi355_upload(mi355_core *core, void *d_dst, const void *host_src, size_t bytes);
 int mi355_download(mi355_core *core, void *host_dst, const void *d_src, size_t bytes);
 

@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/pmc_fw_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 DB="tools/diffbench --steps 3 --warmup 1 $@"
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  MI355_PIPELINE=0 timeout -k 10 200 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/$ctr -- $DB > $OUT/$ctr.log 2>&1 || echo "$ctr pass failed: $(tail -2 $OUT/$ctr.log)"
+  MI355_PIPELINE=0 bash profiles/pmc_pass.sh 200 $OUT/$ctr.log rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/$ctr -- $DB || echo "$ctr pass failed: $(tail -2 $OUT/$ctr.log)"
 done
 python3 - "$OUT" "$TAG" "$*" <<'PY'
 import csv, glob, sys, collections, json

@@ -11,7 +11,8 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM" \
            "GRBM_GUI_ACTIVE SQ_INST_LEVEL_VMEM SQ_THREAD_CYCLES_VALU SQ_IFETCH SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_VALU_MFMA_BUSY_CYCLES" ; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -- $DB > $OUT/g$i.log 2>&1 || echo "group $i failed: $(tail -2 $OUT/g$i.log)"
+  # (profiles/pmc_pass.sh: ends the pass at once when rocprofv3 refuses the counter set instead of waiting for the timeout)
+  bash profiles/pmc_pass.sh 200 $OUT/g$i.log rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -- $DB || echo "group $i failed: $(tail -2 $OUT/g$i.log)"
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections

@@ -18,7 +18,7 @@ ARGS="bench.py --steps $STEPS --warmup 2 --no-cpu --no-pair --no-host-path --no-
 cd $ROOT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || echo "trace failed"
 # counter passes run the C++ harness (same workload, same library, no Python).  They are NOT attempted on
-# `python3 bench.py` any more: that pass crashed in every round (profiles/r02{g,h,i}_pmc_under_python.log) and its
+# `python3 bench.py` any more: that pass crashed in every round (profiles/archive/r02{g,h,i}_pmc_under_python.log) and its
 # cause is known -- see profiles/README.md, "counter passes under PyTorch": the process then holds two HSA/HIP
 # runtimes (PyTorch's bundled ROCm 7.0 copies and the profiler's /opt/rocm 7.2 ones).
 # MI355_PIPELINE=0: one launch of every kernel per batch (a pipelined batch is packed by TWO k_diff_pack launches, half

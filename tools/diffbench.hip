@@ -15,6 +15,7 @@
 //             [--reroll N]              pairs: after the run, N new pairs of output arrays, N new index arrays, N new value
 //                                       arrays, N new cores, N new copies of the frames -- the kernels' times after each
 //                                       (which buffer's placement decides the dense expansion's speed: profiles/README.md)
+//             [--lib-alloc]             the two output arrays from mi355_alloc_outputs (a pair placed for the dense expansion)
 //             [--place N]               pairs: the two output arrays inside ONE allocation, the value array at a sweep of
 //                                       distances behind the index array and the pair at a sweep of displacements; then N
 //                                       pairs of arrays from hipMalloc, from the HIP virtual-memory calls (hipMemCreate: one
@@ -160,6 +161,7 @@ int main(int argc, char **argv) {
     bool pairs = false, filters = false, digest = false, apart = false, print_ptrs = false;
     size_t skew_xs = 0, skew_df = 0, skew_frames = 0;
     int reroll = 0, place = 0;
+    bool lib_alloc = false;   // the two output arrays from mi355_alloc_outputs (a pair placed for the dense expansion)
     const char *corun = nullptr; int corun_blocks = 2048;
     std::vector<std::pair<int, int>> opts;
     const char *regime = nullptr;   // --regime s0|flip|static: pairs of the dense / static regimes (tools/bench_regimes.py's inputs)
@@ -186,6 +188,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--print-ptrs")) print_ptrs = true;
         else if (!strcmp(argv[i], "--reroll")) next(reroll);
         else if (!strcmp(argv[i], "--place")) next(place);
+        else if (!strcmp(argv[i], "--lib-alloc")) lib_alloc = true;
         else if (!strcmp(argv[i], "--opt") && i + 1 < argc) { int id = 0, v = 0; if (sscanf(argv[++i], "%d=%d", &id, &v) == 2) opts.push_back({id, v}); }
     }
     auto apply_opts = [&](mi355_core *c) { for (auto &o : opts) MI_OK(mi355_set_option(c, o.first, o.second)); };
@@ -286,6 +289,8 @@ int main(int argc, char **argv) {
         timed("chain", "config 3: gray-weighted + binarize + diff/threshold/pack", 4 * N, [&]() {
             MI_OK(mi355_filter_batch(core, MI355_OP_GRAY_WEIGHTED_BINARIZE, cur, nullptr, out, n, B));
             MI_OK(mi355_diff_stream_batch(core, cur, n, B, off, xs, df, cap)); });
+        timed("chain", "config 3 in ONE read of the colour frames (mi355_diff_stream_binarize_batch)", 4 * N, [&]() {
+            MI_OK(mi355_diff_stream_binarize_batch(core, cur, n, B, out, n, off, xs, df, cap)); });
         timed("chain", "config 4: noise filter + diff/threshold/pack + red motion map", 5 * N, [&]() {
             MI_OK(mi355_filter_batch(core, MI355_OP_CONV3X3, cur, nullptr, filt, n, B));
             MI_OK(mi355_diff_stream_batch(core, filt, n, B, off, xs, df, cap));
@@ -331,8 +336,16 @@ int main(int argc, char **argv) {
     HIP_OK(hipMalloc((void **)&d_off, sizeof(uint32_t) * (B + 1)));
     // --skew-xs / --skew-df BYTES (multiples of 16): the output arrays displaced inside a larger allocation -- does the
     // expansion's time depend on WHERE its outputs lie (profiles/r05ae_*)?  --print-ptrs shows the addresses.
+    if (lib_alloc) {
+        void *a = nullptr, *b2 = nullptr; int draws = 0;
+        const auto ta = std::chrono::high_resolution_clock::now();
+        MI_OK(mi355_alloc_outputs(core, cap, &a, &b2, &draws));
+        fprintf(stderr, "mi355_alloc_outputs: %d value array(s) drawn in %.1f ms\n", draws, std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - ta).count() * 1e3);
+        d_xs = (int32_t *)a; d_df = (uint8_t *)b2;
+    } else {
     HIP_OK(hipMalloc((void **)&d_xs, sizeof(int32_t) * cap + skew_xs));
     HIP_OK(hipMalloc((void **)&d_df, cap + skew_df));
+    }
     d_xs = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(d_xs) + skew_xs);
     d_df += skew_df;
     if (print_ptrs) fprintf(stderr, "d_xs %p d_df %p d_off %p frames %p\n", (void *)d_xs, (void *)d_df, (void *)d_off, (void *)(pairs ? d_cur : d_frames));
