@@ -1300,6 +1300,104 @@ int mi355_dev_alloc(mi355_core *c, void **out, size_t bytes) {
     return MI355_OK;
 }
 
+// ---- output arrays whose PLACEMENT lets the dense expansion run at its fast speed ---------------------------------------
+// What round 6 found (profiles/README.md, r06a-r06e): when most bytes of a frame change (the synthetic S0 / P = N regimes, a
+// scene cut), k_expand is bound by its stores, and writes the index array and the value array at 5.1 TB/s together when the
+// two streams overlap in the memory system -- or at 4.0 TB/s (265 instead of 205 us per 32 S0 pairs) when they do not.
+// Which of the two a pair of arrays gets is a property of the PAIR's physical memory (it stays with the arrays for their
+// life; another value array beside the same index array re-draws it; between one pair in six and two in three are of the
+// fast kind, box to box; physically contiguous memory is the slowest; the L2's tag stalls and the DRAM-credit stalls of
+// its write requests differ, the request counts do not) -- nothing a caller can see in an address, nothing an offset
+// inside an allocation changes, and a synthetic store kernel of another grid shape mis-predicts it (r06d).  What a caller
+// CAN do is measure with the expansion itself: this call packs a batch of noise frames (P = 0.85 N, the S0 regime) once per
+// candidate value array and keeps the first pair on which k_expand moves its bytes at the fast rate.
+namespace {
+__global__ __launch_bounds__(256) void k_noise_frames(uint32_t *out, size_t nwords, uint32_t seed) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) {
+        uint32_t x = (uint32_t)i * 2654435761u + seed;
+        x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+        out[i] = x;
+    }
+}
+}  // namespace
+
+int mi355_alloc_outputs(mi355_core *c, size_t capacity, void **d_xs, void **d_diff, int *draws_out) {
+    if (!c || !d_xs || !d_diff) return fail(MI355_ERR_INVALID, "null argument");
+    *d_xs = *d_diff = nullptr;
+    if (draws_out) *draws_out = 0;
+    if (c->nslots) return fail(MI355_ERR_STATE, "pipe open");
+    if (int rc = use_device(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t xs_bytes = (capacity ? capacity : 4) * sizeof(int32_t), df_bytes = capacity ? capacity : 16;
+    int32_t *xs = nullptr;
+    HIP_TRY(hipMalloc((void **)&xs, xs_bytes));
+    // the probe: T frames of noise against T other frames of noise, as many as the arrays hold; only worth its while where the
+    // placement matters (a pair of a few hundred MB written by a few thousand expander waves at a time)
+    const size_t N = c->n;
+    int T = c->cfg.max_batch;
+    if (N && (size_t)T * N > capacity) T = (int)(capacity / N);
+    constexpr int kMaxDraws = 32;
+    uint8_t *cand[kMaxDraws] = {};
+    int ndraw = 0, keep = -1;
+    int rc = MI355_OK;
+    if (T >= 8 && (size_t)T * N >= ((size_t)48 << 20) && N % 16 == 0 && 3 * (uint64_t)N + N < (1ull << 32)) {
+        uint8_t *frames = nullptr;
+        uint32_t *off = nullptr;
+        const size_t fbytes = 2 * (size_t)T * N;
+        if (hipMalloc((void **)&frames, fbytes) != hipSuccess || hipMalloc((void **)&off, ((size_t)T + 1) * 4) != hipSuccess) {
+            (void)hipGetLastError();   // no room for the probe: plain allocations
+        } else {
+            hipLaunchKernelGGL(k_noise_frames, dim3(4096), dim3(256), 0, c->stream, (uint32_t *)frames, fbytes / 4, 0x9e3779b9u);
+            const bool was_timing = c->timing;
+            if ((rc = harvest_timing(c)) == MI355_OK) {
+                const double s_pack = c->ms_pack, s_scan = c->ms_scan, s_exp = c->ms_expand, s_tot = c->ms_total;
+                const int s_l = c->launches;
+                double best_rate = 0;
+                while (ndraw < kMaxDraws && rc == MI355_OK) {
+                    if (hipMalloc((void **)&cand[ndraw], df_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+                    uint8_t *df = cand[ndraw++];
+                    // untimed first: ~15 ms of this load on the first candidate (a chip that has been idle needs them to reach
+                    // its clocks), one batch on the others
+                    c->timing = false;
+                    for (int rep = 0; rep < (ndraw == 1 ? 48 : 1) && rc == MI355_OK; rep++)
+                        rc = run_batch(c, true, frames, frames + (size_t)T * N, N, T, off, xs, df, capacity);
+                    c->timing = true;
+                    c->ms_expand = 0; c->launches = 0;
+                    for (int rep = 0; rep < 3 && rc == MI355_OK; rep++)
+                        rc = run_batch(c, true, frames, frames + (size_t)T * N, N, T, off, xs, df, capacity);
+                    if (rc == MI355_OK) rc = harvest_timing(c);
+                    if (rc != MI355_OK) break;
+                    uint32_t total = 0;
+                    if (hipMemcpy(&total, off + T, 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(MI355_ERR_HIP, "hipMemcpy(total)"); break; }
+                    // bytes the expansion moves: the records it reads (16 per lane: T x N) + 5 per entry it writes
+                    const double ms = c->ms_expand / (c->launches ? c->launches : 1);
+                    const double rate = ((double)T * N + 5.0 * total) / (ms * 1e-3);   // bytes per second
+                    if (rate > best_rate) { best_rate = rate; keep = ndraw - 1; }
+                    if (rate >= 4.5e12) break;   // fast pairs: 5.0-5.2 TB/s; slow ones: 3.9-4.1 (profiles/r06*)
+                }
+                c->timing = was_timing;
+                c->ms_pack = s_pack; c->ms_scan = s_scan; c->ms_expand = s_exp; c->ms_total = s_tot; c->launches = s_l;
+            }
+            (void)hipStreamSynchronize(c->stream);
+        }
+        if (frames) (void)hipFree(frames);
+        if (off) (void)hipFree(off);
+    }
+    if (rc == MI355_OK && keep < 0) {   // small arrays, or no room for the probe
+        if (ndraw == 0 && hipMalloc((void **)&cand[0], df_bytes) == hipSuccess) ndraw = 1;
+        keep = ndraw > 0 ? 0 : -1;
+        if (keep < 0) rc = fail(MI355_ERR_HIP, "hipMalloc(value array)");
+    }
+    for (int i = 0; i < ndraw; i++)
+        if (i != keep || rc != MI355_OK) (void)hipFree(cand[i]);
+    if (rc != MI355_OK) { (void)hipFree(xs); return rc; }
+    *d_xs = xs;
+    *d_diff = cand[keep];
+    if (draws_out) *draws_out = ndraw;
+    return MI355_OK;
+}
+
 int mi355_dev_free(mi355_core *c, void *d_ptr) {
     if (!c) return fail(MI355_ERR_INVALID, "null core");
     if (int rc = use_device(c)) return rc;

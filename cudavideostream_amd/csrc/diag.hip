@@ -81,97 +81,9 @@ __global__ __launch_bounds__(256) void k_hbm_write_probe(u32x4 *buf, size_t nvec
     }
 }
 
-// mi355_alloc_outputs' probes: the DENSE expansion's own store shape -- a single-wave workgroup per item, an item = a run of
-// E consecutive entries, 16 bytes of indices and 4 of values per lane and step, non-temporal (diff_pack.hip, flush_entries) --
-// on both arrays (which = 2), the index array alone (0), the value array alone (1).
-__global__ __launch_bounds__(64) void k_items_probe(uint32_t *xs, uint8_t *df, uint32_t E, uint32_t nitems, int which) {
-    const size_t item = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    if (item >= nitems) return;
-    uint32_t *x = xs + item * E;
-    uint8_t *d = df + item * E;
-    for (uint32_t e = threadIdx.x * 4u; e + 3u < E; e += 256u) {
-        const u32x4 v = {e, e + 1u, e + 2u, e + 3u};
-        if (which != 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(x + e));
-        if (which != 0) __builtin_nontemporal_store(e, reinterpret_cast<uint32_t *>(d + e));
-    }
-}
-
 }  // namespace mi355
 
 using namespace mi355;
-
-// ---- output arrays whose PLACEMENT lets the dense expansion run at its fast speed ---------------------------------------
-// What round 6 found (profiles/README.md, r06a-r06c): when most bytes of a frame change (the synthetic S0 / P = N regimes, a
-// scene cut), k_expand is bound by its stores, and writes the index array and the value array at 5.2 TB/s together when the
-// two streams overlap in the memory system -- or no faster than one after the other (4.1 TB/s: 265 instead of 205 us per 32
-// S0 pairs) when they do not.  Which of the two a process gets is a property of the PAIR of arrays' physical memory (it stays
-// with the arrays; another value array beside the same index array re-draws it; about one pair in six is the fast kind;
-// physically contiguous memory is the slowest; the L2's tag stalls and the DRAM-credit stalls of its write requests
-// differ, the request counts do not) -- nothing a caller can see in an address.  What a caller CAN do is measure: this
-// call allocates the index array once and draws value arrays until the expansion's own store shape runs on the pair
-// clearly faster than its two halves one after the other, frees the rejected ones and returns the pair.
-extern "C" int mi355_alloc_outputs(mi355_core *c, size_t capacity, void **d_xs, void **d_diff, int *draws_out) {
-    if (!c || !d_xs || !d_diff) return set_error(MI355_ERR_INVALID, "null argument");
-    *d_xs = *d_diff = nullptr;
-    if (draws_out) *draws_out = 0;
-    if (hipSetDevice(core_device(c)) != hipSuccess) return set_error(MI355_ERR_HIP, "hipSetDevice");
-    const size_t xs_bytes = (capacity ? capacity : 4) * sizeof(int32_t), df_bytes = capacity ? capacity : 16;
-    uint32_t *xs = nullptr;
-    if (hipMalloc((void **)&xs, xs_bytes) != hipSuccess) return set_error(MI355_ERR_HIP, "hipMalloc(index array)");
-    // arrays too small for the placement to matter (the probe needs a few thousand items in flight): plain allocations
-    const uint32_t E = 13824;                       // entries per item: 16 tiles of a dense frame
-    const size_t nitems = capacity / E;
-    constexpr int kMaxDraws = 32;
-    uint8_t *cand[kMaxDraws] = {};
-    int ndraw = 0, keep = -1;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipError_t err = hipSuccess;
-    if (nitems >= 4096) {   // (from ~280 MB for the pair)
-        hipStream_t s = core_stream(c);
-        err = hipEventCreate(&e0);
-        if (err == hipSuccess) err = hipEventCreate(&e1);
-        const dim3 grid(256, (unsigned)((nitems + 255) / 256));
-        auto run = [&](uint8_t *df, int which, float *best) {   // the best of three passes behind a warm-up pass
-            *best = 1e30f;
-            for (int rep = 0; rep < 4 && err == hipSuccess; rep++) {
-                err = hipEventRecord(e0, s);
-                if (err == hipSuccess) { hipLaunchKernelGGL(k_items_probe, grid, dim3(64), 0, s, xs, df, E, (uint32_t)nitems, which); err = hipGetLastError(); }
-                if (err == hipSuccess) err = hipEventRecord(e1, s);
-                if (err == hipSuccess) err = hipEventSynchronize(e1);
-                float ms = 0;
-                if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
-                if (rep > 0 && ms < *best) *best = ms;
-            }
-        };
-        float best_ratio = 1e30f;
-        while (ndraw < kMaxDraws && err == hipSuccess) {
-            if (hipMalloc((void **)&cand[ndraw], df_bytes) != hipSuccess) { (void)hipGetLastError(); break; }   // out of memory: what there is
-            uint8_t *df = cand[ndraw++];
-            float both = 0, only_x = 0, only_d = 0;
-            run(df, 2, &both); run(df, 0, &only_x); run(df, 1, &only_d);
-            if (err != hipSuccess) break;
-            const float ratio = both / (only_x + only_d);   // fast pairs: 0.86; slow ones: 1.03-1.08 (profiles/r06c_*)
-            if (ratio < best_ratio) { best_ratio = ratio; keep = ndraw - 1; }
-            if (ratio < 0.93f) break;
-        }
-    }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (err == hipSuccess && keep < 0) {   // small arrays, or no candidate could be allocated
-        if (ndraw == 0 && hipMalloc((void **)&cand[ndraw], df_bytes) == hipSuccess) ndraw++;
-        keep = ndraw > 0 ? 0 : -1;
-    }
-    for (int i = 0; i < ndraw; i++)
-        if (i != keep || err != hipSuccess) (void)hipFree(cand[i]);
-    if (err != hipSuccess || keep < 0) {
-        (void)hipFree(xs);
-        return set_error(MI355_ERR_HIP, err != hipSuccess ? "mi355_alloc_outputs: probe" : "hipMalloc(value array)");
-    }
-    *d_xs = xs;
-    *d_diff = cand[keep];
-    if (draws_out) *draws_out = ndraw;
-    return MI355_OK;
-}
 
 // One probe: a temporary buffer on the core's device, the kernel four times on the core's stream, the best of the last
 // three passes.  `launch(buffer, bytes, stream)` starts the kernel; returns GB/s of `bytes_counted`.

@@ -640,10 +640,16 @@ typedef uint32_t u32a1 __attribute__((aligned(1)));
 template <bool BYTE_ALIGNED>
 __device__ __forceinline__ void store_out4(uint8_t *p, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
     const u32x4 v = {x, y, z, w};
+    if (kXStore & 2) {   // lab: plain
+        if (BYTE_ALIGNED) *reinterpret_cast<u32x4a1 *>(p) = v;
+        else *reinterpret_cast<u32x4a4 *>(p) = v;
+        return;
+    }
     if (BYTE_ALIGNED) __builtin_nontemporal_store(v, reinterpret_cast<u32x4a1 *>(p));
     else __builtin_nontemporal_store(v, reinterpret_cast<u32x4a4 *>(p));
 }
 __device__ __forceinline__ void store_out1(uint8_t *p, uint32_t v) {   // any byte address
+    if (kXStore & 1) { *reinterpret_cast<u32a1 *>(p) = v; return; }   // lab: plain
     __builtin_nontemporal_store(v, reinterpret_cast<u32a1 *>(p));
 }
 

@@ -349,10 +349,12 @@ int mi355_dev_free(mi355_core *core, void *d_ptr);
  * synthetic worst cases S0 / P = N), the expansion is bound by its stores to these two arrays, and their two streams either
  * overlap in the memory system (205 us per 32 dense 1080p frames) or do not (265): a property of the pair's physical memory
  * that no address shows, the same for the life of the arrays; about one pair in six of plain allocations is the fast kind
- * (round 6, profiles/README.md).  This call allocates the index array, then draws value arrays (at most 32, each probed for
- * ~2 ms with the expansion's own store shape) until the pair is of the fast kind, frees the others and returns the pair;
- * *draws (may be NULL) = value arrays drawn.  Arrays below a few hundred MB of capacity, and sparse streams (a webcam's:
- * the expansion is then bound elsewhere), need none of this: plain allocations.  Free both with mi355_dev_free. */
+ * (round 6, profiles/README.md).  This call allocates the index array, then draws value arrays (at most 32), runs for each
+ * a batch of noise frames (max_batch pairs, P = 0.85 N: ~1 ms) through the core's own kernels into the pair, and keeps the
+ * first pair on which the expansion moves its bytes at the fast rate; the others are freed; *draws (may be NULL) = value
+ * arrays drawn.  Blocking; the core's state and results are untouched (the probe batches are stateless pairs).  Arrays that
+ * hold fewer than 8 frames' worth of entries, and callers of sparse streams (a webcam's: the expansion is then bound
+ * elsewhere), need none of this: plain allocations.  Free both with mi355_dev_free. */
 int mi355_alloc_outputs(mi355_core *core, size_t capacity, void **d_xs, void **d_diff, int *draws);
 int mi355_upload(mi355_core *core, void *d_dst, const void *host_src, size_t bytes);
 int mi355_download(mi355_core *core, void *host_dst, const void *d_src, size_t bytes);
