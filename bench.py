@@ -1331,9 +1331,6 @@ def filter_configs(args, dev, B=192, reps=10):
             core.filter_batch(L.OP_GRAY_WEIGHTED_BINARIZE, cur, vis, B)
             core.diff_stream_batch(cur, B, d_off, d_xs, d_df, cap)
 
-        def config3_one_read():   # the same results from ONE read of the colour frames (mi355_diff_stream_binarize_batch)
-            core.diff_stream_binarize_batch(cur, B, vis, d_off, d_xs, d_df, cap)
-
         def config4():
             core.filter_batch(L.OP_CONV3X3, cur, filt, B)
             core.diff_stream_batch(filt, B, d_off, d_xs, d_df, cap)
@@ -1367,15 +1364,6 @@ def filter_configs(args, dev, B=192, reps=10):
                          "achieved_gbps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4),
                          "basis": "wall clock per frame on the core's own stream (filters of a batch beside the expansion of "
                                   "the batch before); sequential_us_per_frame: the same calls on a caller's stream"}
-        # config 3 both ways, like for like (a caller's stream, one kernel after the other; the one-read form never overlaps batches)
-        core.use_torch_stream()
-        us_two, us_one = wall_us(config3), wall_us(config3_one_read)
-        us_two2, us_one2 = wall_us(config3), wall_us(config3_one_read)
-        res["config3"]["one_read"] = {"us_per_frame": round(min(us_one, us_one2), 3), "two_calls_us_per_frame": round(min(us_two, us_two2), 3),
-                                      "frac": round((3.0 * n + 5.0 * res["config3"]["changed_bytes_per_frame"]) / (min(us_one, us_one2) * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
-                                      "note": "mi355_diff_stream_binarize_batch: the pack kernel also computes the weighted gray value of every pixel "
-                                              "(colour frame read once: 3N + N/2 + N/2 ... bytes moved per frame instead of 4.67 N); alternating "
-                                              "A/B on a caller's stream, the better of two windows each"}
         # the 5x5 median the reference evaluated and left out of its server (tests/noise_filter_benchmark/v3.cu): the one
         # kernel here that is bound by arithmetic (packed 16-bit min / max), not by HBM; N read + N written
         core.use_torch_stream()

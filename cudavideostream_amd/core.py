@@ -231,15 +231,6 @@ class CUDACore:
         _l.check(self._lib.mi355_diff_pairs_batch(self._h, _ptr(d_cur), _ptr(d_prev), stride, nframes,
                                                   _ptr(d_offsets), _ptr(d_xs), _ptr(d_diff), capacity))
 
-    def diff_stream_binarize_batch(self, d_frames, nframes, d_vis, d_offsets, d_xs, d_diff, capacity, stride=None, vis_stride=None):
-        """BASELINE configs[2] in one read of the colour frames (kernels.cu:493-498 then :505): the binarized visualiser
-        frames into d_vis AND the packed diff stream; identical to filter_batch(OP_GRAY_WEIGHTED_BINARIZE) + diff_stream_batch."""
-        self._hold(d_frames, d_vis, d_offsets, d_xs, d_diff)
-        stride = self.total if stride is None else stride
-        vis_stride = self.total if vis_stride is None else vis_stride
-        _l.check(self._lib.mi355_diff_stream_binarize_batch(self._h, _ptr(d_frames), stride, nframes, _ptr(d_vis), vis_stride,
-                                                            _ptr(d_offsets), _ptr(d_xs), _ptr(d_diff), capacity))
-
     # -- the stream either side of the path (wire format, client, row-band merge) -------------------
     def diff_stream_wire_batch(self, d_frames, nframes, d_offsets, d_wire, capacity_bytes, stride=None):
         """threads.cpp:227-229 byte stream of the batch: {u32 n, i32 xs[n], u8 diff[n]} per frame."""

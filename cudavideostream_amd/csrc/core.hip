@@ -70,7 +70,6 @@ struct mi355_core {
     uint32_t *red_bounds = nullptr; // mi355_red_stream_batch (cleared form): entry ranges of the frame slices
     uint8_t *gray1 = nullptr;      // fused gray+binarize chain: one gray byte per pixel of a batch, made on first use
     size_t gray1_stride = 0;
-    uint8_t *gray8 = nullptr;      // mi355_diff_stream_binarize_batch: 8 bytes per 16 frame bytes (PackArgs::gray8), made on first use
     float *k9 = nullptr;
     float *kxk = nullptr;          // mi355_conv_kxk: up to 81 taps, made on first use
     uint8_t *lut = nullptr;
@@ -248,12 +247,6 @@ int need_gray1(mi355_core *c) {
     return dev_alloc(c, &c->gray1, c->gray1_stride * (size_t)c->cfg.max_batch);
 }
 
-// Gray bytes of the one-read config 3 (mi355_diff_stream_binarize_batch): N / 2 per frame, max_batch frames.
-int need_gray8(mi355_core *c) {
-    if (c->gray8 || c->n == 0) return MI355_OK;
-    return dev_alloc(c, &c->gray8, (size_t)c->cfg.max_batch * (c->n / 2) + 16);
-}
-
 // Slice bounds of the cleared red map (mi355_red_stream_batch, clear != 0), max_batch frames: made when first needed.
 int need_red_bounds(mi355_core *c) {
     if (c->red_bounds || c->n == 0) return MI355_OK;
@@ -327,7 +320,7 @@ int setup_pipeline(mi355_core *c) {
 // consumers there must find the batch complete.
 int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, size_t stride,
               int nframes, void *d_offsets, void *d_xs, void *d_diff, size_t capacity,
-              void *d_wire = nullptr, bool pipelined = false, bool want_gray8 = false) {
+              void *d_wire = nullptr, bool pipelined = false) {
     if (!c) return fail(MI355_ERR_INVALID, "null core");
     if (nframes < 0 || nframes > c->cfg.max_batch)
         return fail(MI355_ERR_INVALID, "nframes outside [0, max_batch]");
@@ -391,10 +384,6 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     a.meta = ls.meta;
     a.rec_bytes = (uint32_t)((size_t)c->cfg.max_batch * c->ntiles * 1024u);
     a.meta_bytes = (uint32_t)((size_t)c->cfg.max_batch * c->ntiles * 16u);
-    if (want_gray8) {   // (the caller has checked the geometry and made the buffer)
-        a.gray8 = c->gray8;
-        a.gray8_bytes = (uint32_t)((size_t)c->cfg.max_batch * (c->n / 2));
-    }
     // the vector path of the pack kernel: 16-byte aligned operands, and a group of four frames within reach of one
     // buffer descriptor's 32-bit offsets (diff_pack.hip, Group::load_desc)
     const bool aligned = (((uintptr_t)d_cur | (uintptr_t)d_prev | stride) & 15u) == 0 && 3 * (uint64_t)stride + c->n < (1ull << 32);
@@ -436,10 +425,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
         if (tev) HIP_TRY(hipEventRecord(tev[5], c->main2));   // the pack "kernel" of a split batch ends when BOTH parts have
         c->parts_pending = c->flip;
     } else {
-        // (the one-read config 3 form of the kernel holds 87 registers -- five waves per SIMD, not the six a 1080p frame's tiles
-        // need at one tile per wave --: four workgroups per CU walk the tiles, like the pipelined pack kernel)
-        const uint32_t gray_blocks = c->pack_blocks_opt >= 0 ? (uint32_t)c->pack_blocks_opt : 4u * c->cu_count;
-        HIP_TRY(launch_diff_pack(a, pair, aligned, pair_once, pipelined ? c->k1_blocks : (want_gray8 ? gray_blocks : 0u), c->stream));
+        HIP_TRY(launch_diff_pack(a, pair, aligned, pair_once, pipelined ? c->k1_blocks : 0u, c->stream));
     }
     if (tev) {
         HIP_TRY(hipEventRecord(tev[1], c->stream));
@@ -604,7 +590,7 @@ void mi355_destroy(mi355_core *c) {
         if (c->h_tot) (void)hipHostFree(c->h_tot);
     }
     void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->codes, c->meta, c->groff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
-                    c->lut, c->glyphs, c->kxk, c->gray1, c->gray8, c->red_bounds};
+                    c->lut, c->glyphs, c->kxk, c->gray1, c->red_bounds};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_count) (void)hipHostFree(c->h_count);
     for (auto &slot : c->ev) for (auto &ev : slot) if (ev) (void)hipEventDestroy(ev);
@@ -621,11 +607,8 @@ int mi355_prepare(mi355_core *c, unsigned what) {
     if ((what & MI355_PREPARE_BATCHES) && c->n > 0) {
         if (int rc = setup_pipeline(c)) return rc;   // (a core that cannot have its second set stays sequential: not an error)
     }
-    if (what & MI355_PREPARE_GRAY_CHAIN) {
+    if (what & MI355_PREPARE_GRAY_CHAIN)
         if (int rc = need_gray1(c)) return rc;
-        if (c->cfg.max_batch > 1)   // (the batch entry point's; a per-frame server never calls it)
-            if (int rc = need_gray8(c)) return rc;
-    }
     if (what & MI355_PREPARE_RED_CLEAR)
         if (int rc = need_red_bounds(c)) return rc;
     if ((what & MI355_PREPARE_CONV_KXK) && !c->kxk)
@@ -795,32 +778,6 @@ int mi355_diff_stream_wire_batch(mi355_core *c, const void *d_frames, size_t str
     if (!d_wire) return fail(MI355_ERR_INVALID, "null d_wire");
     return run_batch(c, false, d_frames, nullptr, stride_bytes, nframes, d_offsets, nullptr, nullptr,
                      capacity_bytes, d_wire, true);
-}
-
-// BASELINE configs[2] in ONE read of the colour frames: the pack kernel also leaves the weighted gray value of every pixel
-// (8 bytes per 16 frame bytes), from which the visualiser's histogram, two-max threshold and binarized frames are made
-// (kernels.cu:493-498 then :505).  Geometries the one-read form does not cover (frames that are not whole aligned KiB tiles,
-// batches beyond its 32-bit offsets) take the two calls it replaces.
-int mi355_diff_stream_binarize_batch(mi355_core *c, const void *d_frames, size_t stride_bytes, int nframes, void *d_vis,
-                                     size_t vis_stride_bytes, void *d_offsets, void *d_xs, void *d_diff, size_t capacity) {
-    if (!c) return fail(MI355_ERR_INVALID, "null core");
-    if (nframes < 0 || nframes > c->cfg.max_batch) return fail(MI355_ERR_INVALID, "nframes outside [0, max_batch]");
-    if (nframes > 0 && c->n > 0 && !d_vis) return fail(MI355_ERR_INVALID, "null d_vis");
-    if (nframes > 0 && vis_stride_bytes < c->n) return fail(MI355_ERR_INVALID, "vis_stride_bytes < frame bytes");
-    const bool one_read = c->n > 0 && c->n % kTileBytes == 0 && (((uintptr_t)d_frames | stride_bytes | (uintptr_t)d_vis | vis_stride_bytes) & 15u) == 0 &&
-                          3 * (uint64_t)stride_bytes + c->n < (1ull << 32) && (uint64_t)c->cfg.max_batch * (c->n / 2) < (1ull << 32);
-    if (!one_read) {
-        if (int rc = mi355_filter_batch(c, MI355_OP_GRAY_WEIGHTED_BINARIZE, d_frames, nullptr, d_vis, stride_bytes, nframes)) return rc;
-        // (the filter writes d_vis with the frames' stride: only equal strides can take this way)
-        if (vis_stride_bytes != stride_bytes && nframes > 1) return fail(MI355_ERR_INVALID, "this geometry needs vis_stride_bytes == stride_bytes");
-        return run_batch(c, false, d_frames, nullptr, stride_bytes, nframes, d_offsets, d_xs, d_diff, capacity, nullptr, true);
-    }
-    if (int rc = use_device(c)) return rc;
-    if (int rc = need_gray8(c)) return rc;
-    if (int rc = run_batch(c, false, d_frames, nullptr, stride_bytes, nframes, d_offsets, d_xs, d_diff, capacity, nullptr, false, true)) return rc;
-    if (nframes == 0) return MI355_OK;
-    HIP_TRY(launch_gray8_binarize(c->gray8, c->n, c->ntiles, nframes, c->hist, c->thr, (uint8_t *)d_vis, vis_stride_bytes, c->stream));
-    return MI355_OK;
 }
 
 size_t mi355_wire_bytes(int nframes, uint64_t entries) { return 4 * (size_t)nframes + 5 * (size_t)entries; }

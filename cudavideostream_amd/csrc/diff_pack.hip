@@ -163,46 +163,6 @@ __device__ __forceinline__ uint32_t emit_step(const uint32_t (&dm)[4], uint32_t 
     return nc | (nm << 16);
 }
 
-// ---- config 3 in one read of the colour frame (round 6) ------------------------------------------
-// The visualiser of BASELINE configs[2] (kernels.cu:493-498: weighted gray -> histogram -> two-max -> binarize) needs
-// the gray value of every pixel of the frame the pack kernel is reading anyway.  A pixel is 3 bytes and a lane holds 16, a
-// tile 1024: a lane owns the pixels whose FIRST byte lies in its 16 bytes -- 6 of them when its first byte starts a pixel
-// (phase 0), 5 otherwise -- and gets the one or two bytes its last pixel is short of from the next lane's first dword
-// (DPP wave_shl:1; lane 63: one more dword load, the next tile's first bytes).  (tile + lane) mod 3 gives the phase: 1024
-// and 16 are both 1 mod 3.  The gray value is uint8(0.114 B + 0.587 G + 0.299 R) in double (tests/grayscale-weighted/
-// cpu.cu:40) = floor(K / 1000), K = 114 B + 587 G + 299 R, unless 1000 | K (filters.hip, "weighted gray in integers": proven
-// on all 2^24 triples); the one pixel in a thousand with 1000 | K is evaluated with the double expression itself.
-// K = three chained v_dot4_u32_u8 (587 = 255 + 255 + 77, 299 = 255 + 44: byte weights), floor(K / 1000) = ((K >> 3) *
-// 33555) >> 22.  Returns the lane's 8 bytes {g0 g1 g2 g3, g4 g5 - -}.
-__device__ __forceinline__ uint2 gray_step(const uint4 c, uint32_t nx63, uint32_t phase) {
-    const uint32_t w4 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c.x, 0x130 /* wave_shl:1 */, 0xf, 0xf, true) | nx63;
-    // the 18 bytes from the lane's first pixel on
-    const uint32_t a0 = __builtin_amdgcn_alignbyte(c.y, c.x, phase), a1 = __builtin_amdgcn_alignbyte(c.z, c.y, phase);
-    const uint32_t a2 = __builtin_amdgcn_alignbyte(c.w, c.z, phase), a3 = __builtin_amdgcn_alignbyte(w4, c.w, phase);
-    const uint32_t a4 = w4 >> (8u * phase);
-    // pixel j = bytes 3j .. 3j + 2 of those, moved to the low bytes of a dword (the fourth byte has weight 0)
-    const uint32_t px[6] = {a0, __builtin_amdgcn_alignbyte(a1, a0, 3), __builtin_amdgcn_alignbyte(a2, a1, 2), a2 >> 8, a3,
-                            __builtin_amdgcn_alignbyte(a4, a3, 3)};
-    uint32_t q[6], rem[6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-        const uint32_t K = __builtin_amdgcn_udot4(px[j], 0x00ffff72u, __builtin_amdgcn_udot4(px[j], 0x002cff00u,
-                               __builtin_amdgcn_udot4(px[j], 0x00004d00u, 0u, false), false), false);
-        q[j] = ((K >> 3) * 33555u) >> 22;
-        rem[j] = K - q[j] * 1000u;
-    }
-    const uint32_t least = min(min(min(rem[0], rem[1]), min(rem[2], rem[3])), min(rem[4], rem[5]));
-    if (__ballot(least == 0u)) {   // rare (a pixel in a thousand): the reference's expression itself
-#pragma unroll
-        for (int j = 0; j < 6; j++)
-            if (rem[j] == 0u) {
-                const double v = 0.114 * (double)(px[j] & 0xffu) + 0.587 * (double)((px[j] >> 8) & 0xffu) + 0.299 * (double)((px[j] >> 16) & 0xffu);
-                q[j] = (uint32_t)v;
-            }
-    }
-    return make_uint2(q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24), q[4] | (q[5] << 8));
-}
-
 // A group = kPrefetch consecutive frames of one tile held in registers.  Loads are always issued
 // (frame index clamped to T-1): on gfx950 loads and stores share one in-order vmcnt, and a conditional
 // load makes the compiler fall back to s_waitcnt vmcnt(0) -- i.e. no prefetch.
@@ -211,7 +171,6 @@ struct Group {
     static constexpr int kPrefetch = PrefetchOf<PAIR>::value;
     uint4 c[kPrefetch];
     uint4 p[kPrefetch];
-    uint32_t nx[kPrefetch];   // GRAY: the dword behind the tile (lane 63 only; 0 elsewhere)
 
     // Aligned tiles (round 4): the group's frames through ONE buffer descriptor that starts at the group's first frame
     // and ends with the batch; voff[d] = the lane's byte offset + d * stride.  A frame costs no address arithmetic at
@@ -222,15 +181,12 @@ struct Group {
     // (round-robin shards: pairs (f - 1, f) of every 8th f): non-temporal loads, +7 % for such pairs (0.355 -> 0.332 ms per
     // 128 pairs of 1080p, 4K 0.60 -> 0.63 of the roofline); pairs of CONSECUTIVE frames, where cur of one pair is prev of
     // the next, keep the plain policy (the second read hits): non-temporal loads cost them 6 % (profiles/archive/r04av).
-    template <bool ONCE, bool GRAY = false>
-    __device__ __forceinline__ void load_desc(__amdgpu_buffer_rsrc_t cur, __amdgpu_buffer_rsrc_t prev, const uint32_t (&voff)[kPrefetch],
-                                              const uint32_t (&nxv)[kPrefetch]) {
+    template <bool ONCE>
+    __device__ __forceinline__ void load_desc(__amdgpu_buffer_rsrc_t cur, __amdgpu_buffer_rsrc_t prev, const uint32_t (&voff)[kPrefetch]) {
 #pragma unroll
         for (int d = 0; d < kPrefetch; d++) {
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(cur, voff[d], 0, ONCE ? 2 : 0);
             c[d] = make_uint4(v.x, v.y, v.z, v.w);
-            // lane 63: the dword behind its 16 bytes (the next tile's first); the others: beyond the range -> 0, no traffic
-            if (GRAY) nx[d] = __builtin_amdgcn_raw_buffer_load_b32(cur, nxv[d], 0, 0);
             if (PAIR) {
                 const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(prev, voff[d], 0, ONCE ? 2 : 0);
                 p[d] = make_uint4(w.x, w.y, w.z, w.w);
@@ -256,10 +212,9 @@ struct Group {
     }
 };
 
-template <bool PAIR, bool FAST, bool HIGH, bool GRAY = false>
+template <bool PAIR, bool FAST, bool HIGH>
 __device__ __forceinline__ void pack_group(const PackArgs &a, const Group<PAIR, FAST> &g, int t0, uint4 &st,
-                                           LogPos &lp, uint32_t tile, ThrConst tc, int lane, const LogOut &lg,
-                                           uint32_t phase = 0, __amdgpu_buffer_rsrc_t grays = __amdgpu_buffer_rsrc_t()) {
+                                           LogPos &lp, uint32_t tile, ThrConst tc, int lane, const LogOut &lg) {
     // The group's kPrefetch meta words are assembled in lanes 0..kPrefetch-1 and leave with ONE store.
     constexpr int kPrefetch = PrefetchOf<PAIR>::value;
     uint4 meta = make_uint4(0, 0, 0, 0);
@@ -272,18 +227,6 @@ __device__ __forceinline__ void pack_group(const PackArgs &a, const Group<PAIR, 
         const bool two = t + 1 < a.nframes;
         uint32_t dm0[4], m0, m1 = 0, pc0, pm0, pc1 = 0, pm1 = 0;
         if (PAIR) st = g.p[d];
-        if (GRAY) {   // the visualiser's gray bytes of this frame's pixels (and of the next frame's: the loop takes two)
-            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-            const uint2 g0 = gray_step(g.c[d], g.nx[d], phase);
-            const uint32_t goff = (__umul24((uint32_t)t, a.ntiles) + tile) * 512u + (uint32_t)lane * 8u;
-            const u32x2 v0 = {g0.x, g0.y};
-            __builtin_amdgcn_raw_buffer_store_b64(v0, grays, goff, 0, 0);
-            if (two) {
-                const uint2 g1 = gray_step(g.c[d + 1], g.nx[d + 1], phase);
-                const u32x2 v1 = {g1.x, g1.y};
-                __builtin_amdgcn_raw_buffer_store_b64(v1, grays, goff + a.ntiles * 512u, 0, 0);
-            }
-        }
         compare_step<HIGH>(g.c[d], st, tc, dm0, m0);
         const uint32_t c0 = emit_step(dm0, m0, lg, lp, jump, lane24, pc0, pm0);
         uint32_t c1 = 0;
@@ -314,7 +257,7 @@ __device__ __forceinline__ void pack_group(const PackArgs &a, const Group<PAIR, 
     }
 }
 
-template <bool PAIR, bool FAST, bool HIGH, bool ONCE, bool GRAY = false>
+template <bool PAIR, bool FAST, bool HIGH, bool ONCE>
 __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint32_t byte_off,
                                           int valid, int lane) {
     const int T = a.nframes;
@@ -341,22 +284,16 @@ __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint
             const uint32_t bytes = left <= 0 ? 0u : (left > 0xffffffffll ? 0xffffffffu : (uint32_t)left);
             return make_rsrc(base, bytes);
         };
-        // GRAY: the lane's pixel phase, and where lane 63 finds the two bytes its last pixel may be short of
-        const uint32_t phase = GRAY ? (3u - (tile + (uint32_t)lane) % 3u) % 3u : 0u;
-        uint32_t nxv[kPrefetch];
-#pragma unroll
-        for (int d = 0; d < kPrefetch; d++) nxv[d] = GRAY && lane == 63 ? voff[d] + 16u : kOOB;
-        const __amdgpu_buffer_rsrc_t grays = GRAY ? make_rsrc(a.gray8, a.gray8_bytes) : __amdgpu_buffer_rsrc_t();
-        ga.template load_desc<ONCE, GRAY>(desc(cb), desc(pb), voff, nxv);
+        ga.template load_desc<ONCE>(desc(cb), desc(pb), voff);
         for (int t0 = 0;;) {
             cb += gstep; if (PAIR) pb += gstep; left -= (int64_t)gstep;
-            gb.template load_desc<ONCE, GRAY>(desc(cb), desc(pb), voff, nxv);
-            pack_group<PAIR, FAST, HIGH, GRAY>(a, ga, t0, st, lp, tile, tc, lane, lg, phase, grays);
+            gb.template load_desc<ONCE>(desc(cb), desc(pb), voff);
+            pack_group<PAIR, FAST, HIGH>(a, ga, t0, st, lp, tile, tc, lane, lg);
             t0 += kPrefetch;
             if (t0 >= T) break;
             cb += gstep; if (PAIR) pb += gstep; left -= (int64_t)gstep;
-            ga.template load_desc<ONCE, GRAY>(desc(cb), desc(pb), voff, nxv);
-            pack_group<PAIR, FAST, HIGH, GRAY>(a, gb, t0, st, lp, tile, tc, lane, lg, phase, grays);
+            ga.template load_desc<ONCE>(desc(cb), desc(pb), voff);
+            pack_group<PAIR, FAST, HIGH>(a, gb, t0, st, lp, tile, tc, lane, lg);
             t0 += kPrefetch;
             if (t0 >= T) break;
         }
@@ -385,7 +322,7 @@ __device__ __forceinline__ void pack_tile(const PackArgs &a, uint32_t tile, uint
     }
 }
 
-template <bool PAIR, bool ALIGNED, bool HIGH, bool ONCE = !PAIR, bool GRAY = false>
+template <bool PAIR, bool ALIGNED, bool HIGH, bool ONCE = !PAIR>
 __global__ __launch_bounds__(256) void k_diff_pack(const PackArgs a) {
     const int lane = threadIdx.x & 63;
     // one tile per wave when the grid covers the frame (the default); a smaller grid walks the tiles with its stride
@@ -399,7 +336,7 @@ __global__ __launch_bounds__(256) void k_diff_pack(const PackArgs a) {
         const uint32_t byte_off = tile_off + (uint32_t)lane * 16u;
         // wave-uniform choice: every lane of a full, aligned tile takes the vector path
         if (ALIGNED && tile_off + kTileBytes <= a.n) {
-            pack_tile<PAIR, true, HIGH, ONCE, GRAY>(a, tile, byte_off, 16, lane);
+            pack_tile<PAIR, true, HIGH, ONCE>(a, tile, byte_off, 16, lane);
         } else {
             const int valid = byte_off < a.n ? (int)min(16u, a.n - byte_off) : 0;
             pack_tile<PAIR, false, HIGH, ONCE>(a, tile, byte_off, valid, lane);
@@ -421,10 +358,7 @@ hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, bool pai
         if (high) hipLaunchKernelGGL((k_diff_pack<P, A, true>), grid, block, 0, s, a);                 \
         else hipLaunchKernelGGL((k_diff_pack<P, A, false>), grid, block, 0, s, a);                     \
     } while (0)
-    if (a.gray8) {   // config 3 in one read: stream mode, whole aligned tiles (the caller has checked)
-        if (high) hipLaunchKernelGGL((k_diff_pack<false, true, true, true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_diff_pack<false, true, false, true, true>), grid, block, 0, s, a);
-    } else if (pair) {
+    if (pair) {
         if (aligned && pair_once) {   // operands that share no frame (core.hip, run_batch)
             if (high) hipLaunchKernelGGL((k_diff_pack<true, true, true, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((k_diff_pack<true, true, false, true>), grid, block, 0, s, a);

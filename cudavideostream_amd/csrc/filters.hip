@@ -544,104 +544,6 @@ hipError_t launch_gray_binarize_fused(const uint8_t *color, uint8_t *out, uint32
     return hipGetLastError();
 }
 
-// ---- config 3 in one read of the colour frame: the second half (round 6) --------------------------------------------
-// The pack kernel's GRAY variant (diff_pack.hip, gray_step) leaves 8 bytes per (frame, tile, lane): the gray values of the 5
-// or 6 pixels whose first byte lies in that lane's 16 bytes of the frame (6 when (tile + lane) % 3 == 0), then padding.
-// k_hist_gray8: the frame's histogram from those bytes (N/2 read instead of the colour frame's N; same private LDS bins as
-// k_histogram).  k_binarize_gray8: a lane writes the 16 output bytes of its 16 frame bytes -- `phase` leading bytes
-// belong to the previous lane's last pixel (DPP wave_shr:1; lane 0: one more dword load), then its own pixels three
-// bytes each -- with four v_perm over {binarized gray bytes, that byte}: whole-line coalesced 16-byte stores.
-__device__ __forceinline__ uint32_t gray8_phase(uint32_t packlane) {   // packlane = tile * 64 + lane; 64 = 1 (mod 3)
-    return (3u - ((packlane >> 6) + (packlane & 63u)) % 3u) % 3u;
-}
-
-__global__ __launch_bounds__(256) void k_hist_gray8(const uint8_t *gray8, uint32_t packlanes, int32_t *hist) {
-    __shared__ int32_t bins[4 * kHistReplicas * kHistRow];
-    gray8 += (size_t)blockIdx.y * packlanes * 8u;
-    hist += (size_t)blockIdx.y * 256;
-    int32_t *mine = bins + ((threadIdx.x >> 6) * kHistReplicas + (threadIdx.x & (kHistReplicas - 1))) * kHistRow;
-    // a lane takes 2 pack lanes (16 bytes) per step, kHistBlocks steps, all requested before the bins are cleared
-    uint4 v[kHistBlocks];
-    uint32_t pl[kHistBlocks];
-#pragma unroll
-    for (int it = 0; it < kHistBlocks; it++) {
-        pl[it] = ((blockIdx.x * kHistBlocks + it) * 256u + threadIdx.x) * 2u;
-        v[it] = pl[it] + 1u < packlanes ? *reinterpret_cast<const uint4 *>(gray8 + (size_t)pl[it] * 8u) : make_uint4(0, 0, 0, 0);   // (plain: k_binarize_gray8 reads them again)
-    }
-    for (int i = threadIdx.x; i < 4 * kHistReplicas * kHistRow; i += 256) bins[i] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < kHistBlocks; it++) {
-        if (pl[it] + 1u >= packlanes) continue;   // (packlanes is even: whole tiles)
-        const uint32_t w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t six = gray8_phase(pl[it] + h) == 0u;
-#pragma unroll
-            for (int k = 0; k < 5; k++) atomicAdd(&mine[(w[2 * h + (k >> 2)] >> (8 * (k & 3))) & 0xffu], 1);
-            if (six) atomicAdd(&mine[(w[2 * h + 1] >> 8) & 0xffu], 1);
-        }
-    }
-    __syncthreads();
-    int sum = 0;
-#pragma unroll
-    for (int r = 0; r < 4 * kHistReplicas; r++) sum += bins[r * kHistRow + threadIdx.x];
-    if (sum) atomicAdd(&hist[threadIdx.x], sum);
-}
-
-// 0xff in every byte of x that is > thr (unsigned), 0 elsewhere; cb = (thr + 1) in every byte, thr < 255
-__device__ __forceinline__ uint32_t bytes_above(uint32_t x, uint32_t cb) {
-    const uint32_t t = (x | 0x80808080u) - (cb & 0x7f7f7f7fu);                  // bit 7: x_l >= c_l (no borrow across bytes)
-    // x >= c: (x7 & ~c7) | (~(x7 ^ c7) & t7)
-    const uint32_t ge = __builtin_amdgcn_bitop3_b32(x, cb, t, (0xF0 & ~0xCC) | (~(0xF0 ^ 0xCC) & 0xAA)) & 0x80808080u;
-    return __builtin_amdgcn_perm(0u, 0u, ge);   // selector 0x80 -> 0xff, 0x00 -> byte 0 of the second operand (0)
-}
-
-__global__ __launch_bounds__(256) void k_binarize_gray8(const uint8_t *gray8, uint32_t packlanes, const int32_t *thr_p, uint8_t *out,
-                                                        size_t out_stride) {
-    gray8 += (size_t)blockIdx.y * packlanes * 8u;
-    out += (size_t)blockIdx.y * out_stride;
-    const uint32_t pl = blockIdx.x * 256u + threadIdx.x;   // a wave = a tile (packlanes is a multiple of 64)
-    if (pl >= packlanes) return;                           // wave-uniform
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t cb = ((uint32_t)thr_p[blockIdx.y] + 1u) * 0x01010101u;   // thresholds are 50..200 (server.cpp:122-127)
-    typedef uint32_t v2 __attribute__((ext_vector_type(2)));
-    const v2 gv = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(gray8 + (size_t)pl * 8u));
-    const uint2 g = make_uint2(gv.x, gv.y);
-    // lane 0: the previous tile's last lane's second dword (its last pixel reaches into this tile); others: nothing
-    uint32_t before = 0;
-    if (lane == 0u && pl != 0u) before = *reinterpret_cast<const uint32_t *>(gray8 + (size_t)pl * 8u - 4u);
-    const uint32_t phase = gray8_phase(pl);
-    const uint32_t prev_hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g.y, 0x138 /* wave_shr:1 */, 0xf, 0xf, true) | before;
-    const uint32_t lo = bytes_above(g.x, cb);
-    // the previous lane's last pixel: its gray byte 4 (it holds 5 pixels: this lane's phase is 1) or 5 (6 pixels: phase 2)
-    const uint32_t pbyte = phase == 2u ? prev_hi >> 8 : prev_hi;
-    const uint32_t hi = bytes_above((g.y & 0xffffu) | (pbyte << 16), cb);   // {b4, b5, P, P's neighbour (unused)}
-    // output byte k: k < phase -> P, else pixel (k - phase) / 3.  Selectors of v_perm over {hi: bytes 4..7, lo: bytes 0..3};
-    // P is byte 6
-    const uint32_t s0 = phase == 0u ? 0x01000000u : (phase == 1u ? 0x00000006u : 0x00000606u);
-    const uint32_t s1 = phase == 0u ? 0x02020101u : (phase == 1u ? 0x02010101u : 0x01010100u);
-    const uint32_t s2 = phase == 0u ? 0x03030302u : (phase == 1u ? 0x03030202u : 0x03020202u);
-    const uint32_t s3 = phase == 0u ? 0x05040404u : (phase == 1u ? 0x04040403u : 0x04040303u);
-    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-    const v4 o = {__builtin_amdgcn_perm(hi, lo, s0), __builtin_amdgcn_perm(hi, lo, s1), __builtin_amdgcn_perm(hi, lo, s2),
-                  __builtin_amdgcn_perm(hi, lo, s3)};
-    __builtin_nontemporal_store(o, reinterpret_cast<v4 *>(out + (size_t)pl * 16u));
-}
-
-hipError_t launch_gray8_binarize(const uint8_t *gray8, uint32_t n, uint32_t ntiles, int nframes, int32_t *hist, int32_t *thr,
-                                 uint8_t *out, size_t out_stride, hipStream_t s) {
-    if (nframes <= 0 || n == 0) return hipSuccess;
-    const uint32_t packlanes = ntiles * 64u;   // n is a multiple of 1024 here (core.hip checks)
-    hipError_t e = hipMemsetAsync(hist, 0, (size_t)nframes * 256 * sizeof(int32_t), s);
-    if (e != hipSuccess) return e;
-    const uint32_t per_block = 256u * 2u * kHistBlocks;
-    hipLaunchKernelGGL(k_hist_gray8, dim3((packlanes + per_block - 1) / per_block, (unsigned)nframes), dim3(256), 0, s, gray8, packlanes, hist);
-    hipLaunchKernelGGL(k_two_max_threshold, dim3(nframes), dim3(64), 0, s, hist, thr);
-    hipLaunchKernelGGL(k_binarize_gray8, dim3((packlanes + 255) / 256, (unsigned)nframes), dim3(256), 0, s, gray8, packlanes, thr, out, out_stride);
-    return hipGetLastError();
-}
-
 // ---- heat map: kernels.cu:243-270, CPU tests/heat_map_benchmark/cpu.cu:19-27,54-66 -----------------
 // d = |dB|+|dG|+|dR| (0..765) -> 766-entry BGR look-up table built on the host with the reference's
 // exact double expression; staged in LDS.

@@ -30,11 +30,6 @@ struct PackArgs {
     uint32_t codes_bytes;  // sizes of the logs (buffer descriptors; all < 2^32)
     uint32_t rec_bytes;
     uint32_t meta_bytes;
-    // config 3 in ONE read of the colour frame (stream mode, whole aligned tiles only): the weighted gray value of every
-    // pixel whose FIRST byte lies in a lane's 16 bytes, 8 bytes per (frame, tile, lane) -- 5 or 6 gray bytes + padding --
-    // at gray8 + ((t * ntiles + tile) * 64 + lane) * 8 (diff_pack.hip, gray_step); nullptr: not wanted
-    uint8_t *gray8;
-    uint32_t gray8_bytes;
 };
 
 struct ExpandArgs {
@@ -63,9 +58,6 @@ int core_device(const ::mi355_core *c);
 // diff_pack.hip
 hipError_t launch_diff_pack(const PackArgs &a, bool pair, bool aligned, bool pair_once /* pair mode: no frame is an operand twice */,
                             uint32_t max_blocks /* 0: one tile per wave */, hipStream_t s);
-// the gray bytes a.gray8 of launch_diff_pack -> per-frame histogram -> two-max threshold -> binarized BGR frames
-hipError_t launch_gray8_binarize(const uint8_t *gray8, uint32_t n, uint32_t ntiles, int nframes, int32_t *hist, int32_t *thr,
-                                 uint8_t *out, size_t out_stride, hipStream_t s);
 uint32_t expand_groups(uint32_t ntiles);
 // A frame total travels as ONE 64-bit word {total: 31 bits (a frame is below 2 GiB), tag of the launch: 33 bits}
 // (diff_pack.hip, publish_total).  The tag counts the launches of a core and is never 0 (0 = never written); when it

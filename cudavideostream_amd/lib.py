@@ -64,8 +64,6 @@ SYMBOLS = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi355_diff_stream_wire_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
                                                C.c_void_p, C.c_size_t]),
-    "mi355_diff_stream_binarize_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
-                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi355_wire_bytes": (C.c_size_t, [C.c_int, C.c_uint64]),
     "mi355_apply_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_size_t]),

@@ -202,15 +202,6 @@ int mi355_diff_pairs_batch(mi355_core *core, const void *d_cur, const void *d_pr
                            size_t stride_bytes, int nframes, void *d_offsets, void *d_xs,
                            void *d_diff, size_t capacity);
 
-/* BASELINE configs[2] in ONE read of the colour frames (round 6): mi355_filter_batch(MI355_OP_GRAY_WEIGHTED_BINARIZE) followed
- * by mi355_diff_stream_batch on the same frames -- the visualiser of kernels.cu:493-498 and kernel2 of :505 -- as one call in
- * which the pack kernel also computes the weighted gray value of every pixel it passes (8 scratch bytes per 16 frame bytes,
- * max_batch frames: made on first use or by MI355_PREPARE_GRAY_CHAIN), the histogram / two-max threshold / binarized frames
- * follow from those: N instead of 2N bytes of colour frame read per frame.  d_vis: frame t's binarized BGR frame at d_vis +
- * t * vis_stride_bytes.  Results identical to the two calls.  Runs on the core's stream, one kernel after the other (not
- * overlapped with the next batch).  Frames that are not whole 16-byte aligned KiB tiles take the two calls internally. */
-int mi355_diff_stream_binarize_batch(mi355_core *core, const void *d_frames, size_t stride_bytes, int nframes, void *d_vis,
-                                     size_t vis_stride_bytes, void *d_offsets, void *d_xs, void *d_diff, size_t capacity);
 /* ---- the stream either side of the path ---------------------------------------
  * Wire form of mi355_diff_stream_batch: instead of separate (xs, diff) arrays the batch leaves as the exact
  * byte stream the reference's sender thread writes per frame (server/src/threads.cpp:227-229):

@@ -6,7 +6,7 @@ from cudavideostream_amd import CUDACore as _CUDACore
 
 DEV = "cuda:0"
 
-_DEVICE_CALLS = {"diff_stream_batch", "diff_pairs_batch", "diff_stream_wire_batch", "diff_stream_binarize_batch", "apply_batch",
+_DEVICE_CALLS = {"diff_stream_batch", "diff_pairs_batch", "diff_stream_wire_batch", "apply_batch",
                  "apply_wire_batch", "merge_parts", "int_diff", "gray_avg", "gray_weighted", "binarize_chain",
                  "heat_map", "red_dense", "red_overlap", "red_stream_batch", "conv3x3", "median5x5", "filter_batch"}
 

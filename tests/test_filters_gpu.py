@@ -565,48 +565,6 @@ def test_fused_binarize_vs_reference_fixture():
         assert np.array_equal(d_o.cpu().numpy(), g["out"])
 
 
-@pytest.mark.parametrize("w,h,T", [(1920, 1080, 5), (64, 48, 7), (1024, 3, 4), (97, 13, 3)])
-def test_config3_in_one_read_equals_the_two_calls_and_the_oracle(po, w, h, T):
-    """mi355_diff_stream_binarize_batch (BASELINE configs[2] in ONE read of the colour frames: the pack kernel also leaves the
-    weighted gray value of every pixel, the histogram / two-max threshold / binarized frames follow from those) against the
-    two calls it replaces AND against the oracle: binarized frames, per-frame counts, indices, differences, state.  Frames
-    of whole KiB tiles take the one-read kernels (1080p: 6075 tiles; 64 x 48: 9; 1024 x 3: 9, a tile is not a row); 97 x 13
-    (3783 bytes) takes the two calls internally.  Frame 1 is flat dark and frame 2 flat bright (both clamps of the threshold);
-    the frames hold every pixel phase of a lane (16 = 1 mod 3) and pixels across lane and tile borders."""
-    n = 3 * w * h
-    base, frames = synth.webcam_stream(T, w, h, seed=77, device=DEV)
-    frames = frames.clone()
-    frames[1] = frames[1] // 6
-    frames[2] = 200 + frames[2] // 5
-    # pixels whose 114 B + 587 G + 299 R is a multiple of 1000 (the rare branch of the gray arithmetic): B = G = R = v gives 1000 v
-    frames[0].view(-1, 3)[: min(256, w * h)] = torch.arange(min(256, w * h), device=DEV, dtype=torch.uint8)[:, None]
-    h_base, h_fr = base.cpu().numpy(), frames.cpu().numpy()
-    eo, exs, edf, est = po.diff_stream(h_fr, h_base)
-    cap = T * n
-    outs = []
-    for one_read in (True, False):
-        d_off = torch.zeros(T + 1, dtype=torch.int32, device=DEV)
-        d_xs = torch.full((cap,), -7, dtype=torch.int32, device=DEV)
-        d_df = torch.zeros(cap, dtype=torch.uint8, device=DEV)
-        vis = torch.full((T, n), 0x5A, dtype=torch.uint8, device=DEV)
-        with CUDACore(w, h, max_batch=T, sample_mat_data=h_base) as core:
-            if one_read:
-                core.diff_stream_binarize_batch(frames, T, vis, d_off, d_xs, d_df, cap)
-            else:
-                core.filter_batch(lib.OP_GRAY_WEIGHTED_BINARIZE, frames, vis, T)
-                core.diff_stream_batch(frames, T, d_off, d_xs, d_df, cap)
-            core.synchronize()
-            state = core.get_state()
-        tot = int(eo[-1])
-        outs.append((vis.cpu().numpy(), d_off.cpu().numpy().view(np.uint32), d_xs[:tot].cpu().numpy(), d_df[:tot].cpu().numpy(), state))
-    for vis_o, off, xs, df, state in outs:
-        assert np.array_equal(off, eo) and np.array_equal(xs, exs) and np.array_equal(df, edf) and np.array_equal(state, est)
-        for t in range(T):
-            g3 = po.gray_weighted(h_fr[t])
-            assert np.array_equal(vis_o[t], po.binarize(g3, po.two_max_threshold(po.histogram(g3)))), t
-    assert np.array_equal(outs[0][0], outs[1][0])
-
-
 def test_config3_and_config4_at_1080p(po):
     """BASELINE configs 3 and 4 at full size through exec_core: weighted gray + binarize visualiser,
     and 3x3 noise filter + red motion map, each followed by the diff/threshold/pack."""

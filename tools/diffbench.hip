@@ -289,8 +289,6 @@ int main(int argc, char **argv) {
         timed("chain", "config 3: gray-weighted + binarize + diff/threshold/pack", 4 * N, [&]() {
             MI_OK(mi355_filter_batch(core, MI355_OP_GRAY_WEIGHTED_BINARIZE, cur, nullptr, out, n, B));
             MI_OK(mi355_diff_stream_batch(core, cur, n, B, off, xs, df, cap)); });
-        timed("chain", "config 3 in ONE read of the colour frames (mi355_diff_stream_binarize_batch)", 4 * N, [&]() {
-            MI_OK(mi355_diff_stream_binarize_batch(core, cur, n, B, out, n, off, xs, df, cap)); });
         timed("chain", "config 4: noise filter + diff/threshold/pack + red motion map", 5 * N, [&]() {
             MI_OK(mi355_filter_batch(core, MI355_OP_CONV3X3, cur, nullptr, filt, n, B));
             MI_OK(mi355_diff_stream_batch(core, filt, n, B, off, xs, df, cap));
