@@ -1054,8 +1054,6 @@ def path_line(B, n, p, sec_per_call, ms, launches, pair, sec_pipelined=None):
            "changed_bytes_per_frame": round(p / B, 1), "all_kernels_ms": r["kernel_ms"],
            "achieved_gbps": r["achieved"], "frac": r["frac"],
            "kernels_us": [k["avg_us"] for k in r["kernels"]]}
-    if out["kernels_us"][1] == 0 and out["kernels_us"][2] == 0:
-        out["kernel_path"] = "k_pair_dense: pair mode on dense input in ONE pass, no log (kernels_us: that kernel, 0, 0)"
     if sec_pipelined is not None:
         # ONE method for `frac`, the headline's: the calls on the core's OWN stream, wall clock per call (the library's
         # default way of running: batches overlapped unless its adaptive overlap sees dense input and runs them one after

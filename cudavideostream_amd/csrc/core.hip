@@ -114,10 +114,6 @@ struct mi355_core {
     int median_rows = 0;              // MI355_OPT_MEDIAN_ROWS (0: chosen per launch)
     uint32_t k1_blocks = 0;           // pipelined batches: workgroups of the pack kernel (0 = one tile per wave)
     uint32_t cu_count = 0;            // compute units of the device
-    // pair mode, dense input, one pass (diff_pack.hip, k_pair_dense): its look-back words, made on first use
-    uint64_t *dense_desc = nullptr;
-    uint32_t dense_epoch = 0;         // tag of its last launch, 1 .. 2^30 - 1
-    int dense_pairs = 1;              // MI355_OPT_DENSE_PAIRS: 0 never, 1 while the input is dense (the totals' note), 2 always
     // pipelined batches packed by TWO launches (tiles [0, split) on the core's stream, the rest on `main2`): the two chains
     // of pack kernels drift apart, each one's kernel boundary (L2 write-back, event packets: 21-25 us) falls into the other's
     // kernel.  split_pct = 0: one launch.
@@ -131,9 +127,8 @@ struct mi355_core {
     // expansion; the next calls look at the latest total that HAS ARRIVED (a word of pinned memory the index kernel stores, no
     // waiting) and run one batch after the other while more than dense_pct per cent of the bytes changed.  Results never depend
     // on it, only the schedule.
-    uint64_t *h_tot = nullptr;        // pinned, two words: [0] {entries of the latest batch whose index has run, its frames << 32},
-                                      // stored by that batch's index kernel itself (k_scan_groups / k_pair_dense, `note`);
-                                      // [1] != 0: a look-back of k_pair_dense gave up (DenseArgs::err)
+    uint64_t *h_tot = nullptr;        // pinned: {entries of the latest own-stream batch whose index has run, its frames << 32},
+                                      // stored by that batch's index kernel itself (k_scan_groups, `note`)
     int dense_pct = 40;               // MI355_OPT_DENSE_PCT (0: never switch)
     bool dense = false;               // what the latest total that has arrived said
     bool filter_since_batch = false;  // a frame filter ran on this core since the last batch (use_device_filter)
@@ -252,15 +247,6 @@ int need_gray1(mi355_core *c) {
     return dev_alloc(c, &c->gray1, c->gray1_stride * (size_t)c->cfg.max_batch);
 }
 
-// Look-back words of the one-pass dense form of pair mode: one per 32 tiles (a workgroup) of every frame of a batch.
-int need_dense(mi355_core *c) {
-    if (c->dense_desc || c->n == 0) return MI355_OK;
-    const size_t units = (size_t)c->cfg.max_batch * ((c->ntiles + kDenseUnitTiles - 1) / kDenseUnitTiles);
-    if (int rc = dev_alloc(c, &c->dense_desc, units)) return rc;
-    HIP_TRY(hipMemset(c->dense_desc, 0, units * sizeof(uint64_t)));   // tag 0 = never written
-    return MI355_OK;
-}
-
 // Slice bounds of the cleared red map (mi355_red_stream_batch, clear != 0), max_batch frames: made when first needed.
 int need_red_bounds(mi355_core *c) {
     if (c->red_bounds || c->n == 0) return MI355_OK;
@@ -349,45 +335,11 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
         if (int rc = setup_pipeline(c)) return rc;
         pipelined = c->pipeline_ok;
     }
-    if (c->h_tot && c->dense_pct > 0 && c->dense_pct < 100) {
+    if (pipelined && c->h_tot && c->dense_pct > 0 && c->dense_pct < 100) {
         // the latest batch total that has arrived: dense input -> this batch runs after the expansion of the one before
         const uint64_t note = __atomic_load_n(c->h_tot, __ATOMIC_RELAXED);   // one 64-bit word: never torn
         if (note >> 32) c->dense = (note & 0xffffffffull) * 100u > (uint64_t)c->dense_pct * (note >> 32) * c->n;
         if (c->dense) pipelined = false;   // (no total has arrived yet: what the last one said still holds)
-    }
-    if (c->h_tot && __atomic_load_n(c->h_tot + 1, __ATOMIC_RELAXED))
-        return fail(MI355_ERR_STATE, "k_pair_dense: a look-back gave up in an earlier batch (its results are wrong); MI355_OPT_DENSE_PAIRS 0 avoids the kernel");
-    // Pair mode on dense input in ONE pass (no log: 2N + 5P bytes instead of 4N + 5P): while the totals say the input is
-    // dense (or always: MI355_OPT_DENSE_PAIRS 2), for operands the kernel's 16-byte loads can take
-    const bool one_pass = pair && !d_wire && nframes > 0 && c->n > 0 && c->dense_pairs != 0 && (c->dense_pairs == 2 || c->dense) &&
-                          c->n % 16 == 0 && (((uintptr_t)d_cur | (uintptr_t)d_prev | stride) & 15u) == 0;
-    if (one_pass) {
-        if (int rc = use_device(c)) return rc;
-        if (int rc = need_dense(c)) return rc;
-        if (++c->dense_epoch >= kDenseEpochWrap) {   // the tags have wrapped: every word goes before a tag is used again
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            HIP_TRY(hipMemset(c->dense_desc, 0, (size_t)c->cfg.max_batch * ((c->ntiles + kDenseUnitTiles - 1) / kDenseUnitTiles) * sizeof(uint64_t)));
-            c->dense_epoch = 1;
-        }
-        hipEvent_t *tev = nullptr;
-        if (c->timing) {
-            if (int rc = harvest_timing(c, mi355_core::kEvRing - 1)) return rc;
-            tev = c->ev[(c->ev_head + c->ev_count) % mi355_core::kEvRing];
-            c->ev_split[(c->ev_head + c->ev_count) % mi355_core::kEvRing] = false;
-            HIP_TRY(hipEventRecord(tev[0], c->stream));
-        }
-        DenseArgs d{};
-        d.cur = (const uint8_t *)d_cur; d.prev = (const uint8_t *)d_prev; d.stride = stride; d.n = c->n; d.nframes = nframes;
-        d.thr = c->cfg.threshold; d.ntiles = c->ntiles; d.desc = c->dense_desc; d.epoch = c->dense_epoch;
-        d.offsets = (uint32_t *)d_offsets; d.out_xs = (int32_t *)d_xs; d.out_diff = (uint8_t *)d_diff; d.capacity = capacity;
-        d.note = c->dense_pct > 0 && c->dense_pct < 100 ? c->h_tot : nullptr;
-        d.err = (uint32_t *)(c->h_tot + 1);
-        HIP_TRY(launch_pair_dense(d, c->stream));
-        if (tev) {   // (the whole path is this one kernel: it counts as the "pack" time, the index and the expansion as 0)
-            for (int i = 1; i <= 4; i++) HIP_TRY(hipEventRecord(tev[i], c->stream));
-            c->ev_count += 1;
-        }
-        return MI355_OK;
     }
     if (!pipelined)
         if (int rc = use_device(c)) return rc;
@@ -495,8 +447,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
     }
     // (an own-stream batch leaves its total in pinned memory for the next calls' decisions -- stored by the index kernel
     // itself: a copy + an event behind every batch cost config 3's chain 4 %, the event's system-scope fence included)
-    (void)own;
-    uint64_t *const note = c->h_tot && c->dense_pct > 0 && c->dense_pct < 100 ? c->h_tot : nullptr;
+    uint64_t *const note = own && c->h_tot && c->pipeline_ok && c->dense_pct > 0 && c->dense_pct < 100 ? c->h_tot : nullptr;
     HIP_TRY(launch_scan(ls.meta, ls.groff, (uint64_t *)ls.totals, c->ntiles, nframes, (uint32_t *)d_offsets,
                         ls.totals + 2 * (size_t)c->cfg.max_batch, c->scan_epoch, note, tail));
     if (tev) HIP_TRY(hipEventRecord(tev[3], tail));
@@ -601,7 +552,7 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (!rc) rc = dev_alloc(c, &c->k9, 9);
     if (!rc) rc = dev_alloc(c, &c->lut, 768 * 3);
     if (!rc) { e = hipHostMalloc((void **)&c->h_count, 2 * sizeof(uint32_t), hipHostMallocDefault); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipHostMalloc", e); }
-    if (!rc) { e = hipHostMalloc((void **)&c->h_tot, 2 * sizeof(uint64_t), hipHostMallocDefault); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipHostMalloc", e); else c->h_tot[0] = c->h_tot[1] = 0; }
+    if (!rc) { e = hipHostMalloc((void **)&c->h_tot, sizeof(uint64_t), hipHostMallocDefault); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipHostMalloc", e); else *c->h_tot = 0; }
     if (!rc) { e = hipMemset(c->state, 0, N + 16); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipMemset", e); }
     if (!rc) {
         uint8_t lut[768 * 3] = {0};
@@ -637,7 +588,7 @@ void mi355_destroy(mi355_core *c) {
         if (c->h_tot) (void)hipHostFree(c->h_tot);
     }
     void *ptrs[] = {c->state, c->in, c->aux, c->vis, c->rec, c->codes, c->meta, c->groff, c->totals, c->offsets, c->one_xs, c->one_diff, c->hist, c->thr, c->k9,
-                    c->lut, c->glyphs, c->kxk, c->gray1, c->red_bounds, c->dense_desc};
+                    c->lut, c->glyphs, c->kxk, c->gray1, c->red_bounds};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_count) (void)hipHostFree(c->h_count);
     for (auto &slot : c->ev) for (auto &ev : slot) if (ev) (void)hipEventDestroy(ev);
@@ -653,7 +604,6 @@ int mi355_prepare(mi355_core *c, unsigned what) {
     if (int rc = use_device(c)) return rc;
     if ((what & MI355_PREPARE_BATCHES) && c->n > 0) {
         if (int rc = setup_pipeline(c)) return rc;   // (a core that cannot have its second set stays sequential: not an error)
-        if (int rc = need_dense(c)) return rc;
     }
     if (what & MI355_PREPARE_GRAY_CHAIN)
         if (int rc = need_gray1(c)) return rc;
@@ -738,10 +688,6 @@ int mi355_set_option(mi355_core *c, int option, int value) {
             if (value < 0 || value > 60 || value % 5) return fail(MI355_ERR_INVALID, "MI355_OPT_MEDIAN_ROWS: 0 (default) or 5, 10, .. 60");
             c->median_rows = value;
             return MI355_OK;
-        case MI355_OPT_DENSE_PAIRS:
-            if (value < 0 || value > 2) return fail(MI355_ERR_INVALID, "MI355_OPT_DENSE_PAIRS: 0 (never), 1 (while the input is dense) or 2 (always)");
-            c->dense_pairs = value;
-            return MI355_OK;
         case MI355_OPT_SCAN_EPOCH_LEFT:   // tests: the index kernel's launch tag this many launches before its wrap
             if (value < 1 || value > (1 << 30)) return fail(MI355_ERR_INVALID, "MI355_OPT_SCAN_EPOCH_LEFT: 1..2^30");
             if (c->side) HIP_TRY(hipStreamSynchronize(c->side));
@@ -760,7 +706,6 @@ int mi355_get_option(mi355_core *c, int option, int *value) {
         case MI355_OPT_CHAIN_HINT: *value = c->chain_hint ? 1 : 0; return MI355_OK;
         case MI355_OPT_PACK_BLOCKS: *value = c->pack_blocks_opt; return MI355_OK;
         case MI355_OPT_MEDIAN_ROWS: *value = c->median_rows; return MI355_OK;
-        case MI355_OPT_DENSE_PAIRS: *value = c->dense_pairs; return MI355_OK;
         case MI355_OPT_SCAN_EPOCH_LEFT: {
             const uint64_t left = kEpochWrap - 1 - c->scan_epoch;
             *value = left > (1ull << 30) ? (1 << 30) : (int)left;

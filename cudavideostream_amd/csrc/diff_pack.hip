@@ -961,165 +961,6 @@ __global__ __launch_bounds__(64 * kXWaves) __attribute__((amdgpu_waves_per_eu(8,
     if (kXAblate < 2) flush_entries<WIRE>(a, s_stage, 0u, nent, xs0, dst0, w_xs, w_df, w_room);
 }
 
-// ---- pair mode, dense input, ONE pass (round 6) -----------------------------------------------------------
-// When most bytes of a frame change (the synthetic S0 / P = N regimes, a scene cut) the log is as large as the frames: the
-// two-pass path moves 2N + N (records written) + N (records read) + 5P.  Pairs carry no state from frame to frame, so a wave
-// that knew how many entries lie in front of its tiles could write its entries itself: 2N + 5P, the algorithmic bytes.
-// k_pair_dense: a wave = kDenseTiles consecutive tiles of ONE pair, a workgroup = kDenseWaves waves = a UNIT (units in
-// frame-major order = output order); compare as k_diff_pack does, count, then DECOUPLED LOOK-BACK along the units: wave 0 of
-// every unit publishes its count as one 64-bit word {value, tag of the launch, status: aggregate / inclusive prefix} (one
-// atomic object carries value and "it is there": no fence, as publish_total), reads the words of the 128 units in front of
-// it at once, and adds up aggregates back to the nearest inclusive prefix.  Its entries then go through the expander's own stage (walk_records / flush_entries) or, for a
-// tile with all 1024 bytes flagged, straight out.  Forward progress: workgroups are dealt to the XCDs round-robin by linear
-// id and started in order on each (what launch_expand's grid padding already rests on), so the lowest unfinished unit is
-// always resident and waits for nobody; a look-back that does not resolve in ~10^6 polls gives up and raises a.err instead
-// of hanging the GPU (never seen).
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane(wave_inclusive_scan((int)v), 63); }
-
-template <bool HIGH>
-__global__ __launch_bounds__(64 * kDenseWaves) void k_pair_dense(const DenseArgs a) {
-    // A UNIT of the look-back chain is a workgroup: kDenseWaves waves x kDenseTiles tiles = 32 consecutive tiles of one pair.
-    // (The first version chained single waves of four tiles: 48 600 units per 32 frames of 1080p arrive at 140 per
-    // microsecond, a chain link resolves 64 units per poll of ~1.5 us = 43 per microsecond -- the look-back fell behind
-    // until every resident wave waited for it: 351 us per batch against 321 for the two-pass path, profiles/r06g.)
-    __shared__ __attribute__((aligned(16))) uint32_t s_stages[kDenseWaves][kWStage];
-    __shared__ uint32_t s_tot[kDenseWaves], s_excl;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint32_t *const stage = s_stages[wave];
-    const uint32_t upf = (a.ntiles + kDenseUnitTiles - 1u) / kDenseUnitTiles;   // units per frame
-    const uint32_t nunits = upf * (uint32_t)a.nframes;
-    const uint32_t unit = blockIdx.x;                                           // global order = output order
-    const uint32_t t = unit / upf, k = unit - t * upf;
-    const uint32_t tile0 = k * kDenseUnitTiles + wave * kDenseTiles;
-    // the frames of pair t through descriptors that end with the frame: tiles beyond it read zeros (cur == prev: nothing flagged)
-    const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.cur + (size_t)t * a.stride, a.n), rp = make_rsrc(a.prev + (size_t)t * a.stride, a.n);
-    uint4 c[kDenseTiles], p[kDenseTiles];
-#pragma unroll
-    for (uint32_t i = 0; i < kDenseTiles; i++) {
-        const uint32_t off = (tile0 + i) * kTileBytes + lane * 16u;
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, 2), w = __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 2);
-        c[i] = make_uint4(v.x, v.y, v.z, v.w);
-        p[i] = make_uint4(w.x, w.y, w.z, w.w);
-    }
-    const ThrConst tc = make_thr((uint32_t)a.thr);
-    uint32_t dm[kDenseTiles][4], m16[kDenseTiles], before[kDenseTiles], tot[kDenseTiles], mine = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < kDenseTiles; i++) {
-        compare_step<HIGH>(c[i], p[i], tc, dm[i], m16[i]);
-        const uint32_t cnt = (uint32_t)__builtin_popcount(m16[i]);
-        const uint32_t incl = (uint32_t)wave_inclusive_scan((int)cnt);
-        before[i] = incl - cnt;                                          // entries of the tile in front of this lane's
-        tot[i] = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);     // wave-uniform
-        mine += tot[i];
-        __builtin_amdgcn_sched_barrier(0);   // one tile after the other: interleaved, the four compares need 128 registers
-    }
-    if (lane == 0u) s_tot[wave] = mine;
-    __syncthreads();
-    // ---- the entries in front of this unit: wave 0 looks back ----------------------------------------------------------
-    if (wave == 0u) {
-        uint32_t agg = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < kDenseWaves; w++) agg += s_tot[w];
-        const uint64_t tag = (uint64_t)a.epoch << 32;
-        constexpr uint64_t kAggregate = 1ull << 62, kPrefix = 2ull << 62;
-        if (lane == 0u)
-            __hip_atomic_store(&a.desc[unit], (uint64_t)agg | tag | (unit == 0u ? kPrefix : kAggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t excl = 0;
-        if (unit != 0u) {
-            int64_t base = (int64_t)unit - 1;   // lane L looks at units base - L and base - 64 - L
-            uint32_t polls = 0;
-            for (;;) {
-                if (++polls > (1u << 20)) {              // not reached in any run; a bug must not hang the GPU
-                    if (lane == 0u) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    break;
-                }
-                const int64_t i0 = base - (int64_t)lane, i1 = i0 - 64;
-                // (units in front of the first: an inclusive prefix of 0)
-                const uint64_t w0 = i0 >= 0 ? __hip_atomic_load(&a.desc[i0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (tag | kPrefix);
-                const uint64_t w1 = i1 >= 0 ? __hip_atomic_load(&a.desc[i1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (tag | kPrefix);
-                const bool there0 = (w0 & 0x3fffffff00000000ull) == tag && (w0 >> 62) != 0u;
-                const bool there1 = (w1 & 0x3fffffff00000000ull) == tag && (w1 >> 62) != 0u;
-                const uint64_t b_there0 = __ballot(there0), b_prefix0 = __ballot(there0 && (w0 >> 62) == 2u);
-                const uint32_t gap0 = ~b_there0 ? (uint32_t)__builtin_ctzll(~b_there0) : 64u;
-                const uint32_t pre0 = b_prefix0 ? (uint32_t)__builtin_ctzll(b_prefix0) : 64u;
-                if (pre0 < gap0) {                       // aggregates up to the nearest inclusive prefix: done
-                    excl += wave_sum(lane <= pre0 ? (uint32_t)w0 : 0u);
-                    break;
-                }
-                if (gap0 == 64u) {                       // 64 aggregates and no prefix among them: the 64 behind them
-                    excl += wave_sum((uint32_t)w0);
-                    const uint64_t b_there1 = __ballot(there1), b_prefix1 = __ballot(there1 && (w1 >> 62) == 2u);
-                    const uint32_t gap1 = ~b_there1 ? (uint32_t)__builtin_ctzll(~b_there1) : 64u;
-                    const uint32_t pre1 = b_prefix1 ? (uint32_t)__builtin_ctzll(b_prefix1) : 64u;
-                    if (pre1 < gap1) {
-                        excl += wave_sum(lane <= pre1 ? (uint32_t)w1 : 0u);
-                        break;
-                    }
-                    if (gap1 == 64u) {                   // and 64 more aggregates
-                        excl += wave_sum((uint32_t)w1);
-                        base -= 128;
-                    } else {
-                        base -= 64;                      // (the first 64 are in the sum; the next look starts behind them)
-                    }
-                    continue;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if (lane == 0u)
-                __hip_atomic_store(&a.desc[unit], (uint64_t)(excl + agg) | tag | kPrefix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (lane == 0u) {
-            s_excl = excl;
-            if (k == 0u) a.offsets[t] = excl;
-            if (unit == nunits - 1u) {
-                a.offsets[a.nframes] = excl + agg;
-                if (a.note) __hip_atomic_store(a.note, (uint64_t)(excl + agg) | ((uint64_t)(uint32_t)a.nframes << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
-    __syncthreads();
-    if (mine == 0u) return;   // wave-uniform (no barrier follows)
-    uint32_t dst = s_excl;
-    for (uint32_t w = 0; w < wave; w++) dst += s_tot[w];
-    // ---- the entries themselves, tile by tile --------------------------------------------------------------------------
-    ExpandArgs ea{};
-    ea.out_xs = a.out_xs;
-    ea.out_diff = a.out_diff;
-    ea.capacity = a.capacity;
-#pragma unroll
-    for (uint32_t i = 0; i < kDenseTiles; i++) {
-        if (tot[i] == 0u) continue;   // wave-uniform
-        const uint32_t xs0 = (tile0 + i) * kTileBytes;
-        if (tot[i] == kTileBytes && (size_t)dst + kTileBytes <= a.capacity) {
-            // every byte flagged: the lanes' masked differences ARE the tile's values in order, its indices are consecutive
-            uint8_t *xsp = (uint8_t *)(a.out_xs + (size_t)dst), *dfp = a.out_diff + (size_t)dst;
-            const uint32_t x = xs0 + 4u * lane;
-#pragma unroll
-            for (uint32_t q = 0; q < 4; q++)
-                store_out4<true>(xsp + 1024 * q + 16 * lane, x + 256 * q, x + 256 * q + 1, x + 256 * q + 2, x + 256 * q + 3);
-            store_out4<true>(dfp + 16 * lane, dm[i][0], dm[i][1], dm[i][2], dm[i][3]);
-        } else {
-            walk_records(m16[i], before[i], lane * 16u, make_uint4(dm[i][0], dm[i][1], dm[i][2], dm[i][3]), stage, lane);
-            lds_handoff();
-            flush_entries<false>(ea, stage, 0u, tot[i], xs0, dst, nullptr, nullptr, 0);
-            lds_handoff();   // the stage is rewritten by the next tile
-        }
-        dst += tot[i];
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-hipError_t launch_pair_dense(const DenseArgs &a, hipStream_t s) {
-    const uint32_t upf = (a.ntiles + kDenseUnitTiles - 1u) / kDenseUnitTiles;
-    const uint32_t nunits = upf * (uint32_t)a.nframes;
-    if (nunits == 0) return hipSuccess;
-    const dim3 grid(nunits), block(64 * kDenseWaves);
-    if (a.thr >= 128) hipLaunchKernelGGL((k_pair_dense<true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_pair_dense<false>), grid, block, 0, s, a);
-    return hipGetLastError();
-}
-
 hipError_t launch_expand(const ExpandArgs &a, int nframes, hipStream_t s) {
     static_assert(kWTiles * 4u == kXTiles, "k_scan_groups writes four range prefixes per group");
     // Workgroups go to the 8 XCDs round-robin by linear id: with grid.x a multiple of 8 the items of one tile range

@@ -47,30 +47,6 @@ struct ExpandArgs {
     size_t capacity;          // entries of out_xs/out_diff, or bytes of wire
 };
 
-// One-pass form of pair mode for DENSE input (diff_pack.hip, k_pair_dense): no log -- a wave compares four tiles of one pair,
-// learns the entries in front of them by looking back along a chain of per-wave descriptors, and writes its entries itself.
-struct DenseArgs {
-    const uint8_t *cur, *prev;   // pair t at cur + t * stride, prev + t * stride (16-byte aligned, like stride)
-    size_t stride;
-    uint32_t n;                  // bytes per frame
-    int32_t nframes;
-    int32_t thr;
-    uint32_t ntiles;
-    uint64_t *desc;              // [nframes * ceil(ntiles / 32)] look-back words {value: 32, tag of the launch: 30, status: 2}
-    uint32_t epoch;              // this launch's tag, 1 .. 2^30 - 1
-    uint32_t *offsets;           // [nframes + 1] out
-    int32_t *out_xs;
-    uint8_t *out_diff;
-    size_t capacity;
-    uint64_t *note;              // pinned host word for {batch total, frames << 32}, or nullptr
-    uint32_t *err;               // pinned host word: set to 1 when a look-back gave up (never seen; it keeps a bug from hanging the GPU)
-};
-constexpr uint32_t kDenseTiles = 4;       // tiles per wave of k_pair_dense
-constexpr uint32_t kDenseWaves = 4;       // waves per workgroup = per unit of its look-back chain (32 tiles)
-constexpr uint32_t kDenseUnitTiles = kDenseTiles * kDenseWaves;
-constexpr uint32_t kDenseEpochWrap = 1u << 30;
-hipError_t launch_pair_dense(const DenseArgs &a, hipStream_t s);
-
 // core.hip, for the other translation units of the library (group.hip)
 }  // namespace mi355
 struct mi355_core;

@@ -139,11 +139,6 @@ int mi355_synchronize(mi355_core *core);
 #define MI355_OPT_MEDIAN_ROWS 6  /* 0 (default): the 5x5 median's column-strip kernel walks bands of 5..60 rows, chosen per launch
                                   * (from 20 rows up the length that wastes least of the frame's last pair of bands; shorter
                                   * when that makes fewer than a few thousand waves); 5, 10, .. 60: this many */
-#define MI355_OPT_DENSE_PAIRS 8   /* 1 (default): mi355_diff_pairs_batch takes its ONE-PASS form (no log between two kernels: a wave
-                                  * looks back along a chain of per-wave counts and writes its entries itself; 2N + 5P bytes moved
-                                  * instead of 4N + 5P) while the batch totals say that more than MI355_OPT_DENSE_PCT per cent of the
-                                  * bytes change (a scene cut, the synthetic worst cases); 0: never; 2: always (the tests).  Results
-                                  * are identical either way. */
 #define MI355_OPT_SCAN_EPOCH_LEFT 7 /* tests only: launches of the index kernel left before its 33-bit launch tag wraps (the
                                   * totals are then cleared behind a synchronisation and the tag restarts at 1); set: 1..2^30 */
 int mi355_set_option(mi355_core *core, int option, int value);

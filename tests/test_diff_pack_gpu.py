@@ -154,95 +154,6 @@ def test_pairs_of_consecutive_frames_and_of_disjoint_frames(po):
             assert np.array_equal(off, eo) and np.array_equal(xs, exs) and np.array_equal(df, edf)
 
 
-# ---- pair mode in ONE pass (k_pair_dense: no log, look-back along the waves) --------------------------------------------
-def _pairs_for(kind, n, T, w, h):
-    if kind == "s0":          # the generator of tests/algorithms_benchmarks.cu:4-10: P ~ 0.85 N
-        cur = np.stack([synth.refrand_frame(n, 300 + t) for t in range(T)])
-        prev = np.stack([synth.refrand_frame(n, 400 + t) for t in range(T)])
-    elif kind == "flip":      # every byte changes: the full-tile stores
-        prev = np.stack([synth.refrand_frame(n, 500 + t) for t in range(T)])
-        cur = prev ^ 0x80
-    elif kind == "static":    # nothing changes
-        prev = np.stack([synth.refrand_frame(n, 600 + t) for t in range(T)])
-        cur = prev.copy()
-    elif kind == "webcam":    # sparse: isolated bytes and an object's edges
-        _, fr = synth.webcam_stream(2 * T, w, h, seed=88)
-        cur, prev = np.ascontiguousarray(fr[1::2]), np.ascontiguousarray(fr[0::2])
-    else:                     # mixed: frames of every kind in one batch, a still frame in the middle
-        cur, prev = _pairs_for("s0", n, T, w, h)
-        f_c, f_p = _pairs_for("flip", n, T, w, h)
-        w_c, w_p = _pairs_for("webcam", n, T, w, h)
-        for t in range(T):
-            if t % 4 == 1:
-                cur[t], prev[t] = f_c[t], f_p[t]
-            elif t % 4 == 2:
-                cur[t], prev[t] = w_c[t], w_p[t]
-            elif t % 4 == 3:
-                cur[t] = prev[t]
-    return cur, prev
-
-
-@pytest.mark.parametrize("w,h,T", [(320, 180, 9), (64, 48, 5), (16, 3, 3), (1000, 4, 6), (1360, 1, 4)])
-@pytest.mark.parametrize("kind", ["s0", "flip", "static", "webcam", "mixed"])
-def test_pairs_in_one_pass_equal_the_oracle(po, kind, w, h, T):
-    """MI355_OPT_DENSE_PAIRS 2: every pair batch through k_pair_dense (four tiles per wave, decoupled look-back along the
-    waves, entries written by the wave itself) -- dense, full, still, sparse and mixed frames; frames of whole tiles, of a
-    last partial tile (1000 x 4: 11.7 tiles), of less than a wave's four tiles (16 x 3: 144 bytes) and of a tile count that
-    is not a multiple of four -- against the oracle, twice (the second launch finds the first one's words: other tags)."""
-    n = 3 * w * h
-    assert n % 16 == 0
-    cur, prev = _pairs_for(kind, n, T, w, h)
-    eo, exs, edf = oracle_pairs(po, cur, prev)
-    with CUDACore(w, h, max_batch=T) as core:
-        core.set_option(lib.OPT_DENSE_PAIRS, 2)
-        for own in (True, False):
-            if not own:
-                core.use_torch_stream()
-            for _ in range(2):
-                off, xs, df, _ = run_stream(core, cur, pair_prev=prev)
-                assert np.array_equal(off, eo), (kind, own)
-                assert np.array_equal(xs, exs) and np.array_equal(df, edf), (kind, own)
-        assert core.get_option(lib.OPT_DENSE_PAIRS) == 2
-
-
-def test_pairs_in_one_pass_thresholds_capacity_and_the_automatic_choice(po):
-    """The one-pass form at thresholds either side of 128 on every byte pair, with a capacity that cuts inside a frame
-    (offsets stay exact, entries beyond it are dropped), and chosen BY ITSELF (the default, MI355_OPT_DENSE_PAIRS 1): a core
-    that has seen a dense batch's total takes it for the next pair batch and leaves it again after a sparse one -- results
-    equal the oracle whichever kernel ran."""
-    a, b = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8))
-    cur, prev = a.reshape(1, -1).copy(), b.reshape(1, -1).copy()        # 65 536 bytes = a 128 x 170.67 ... use w = 4096, h = 16 / 3
-    n = cur.shape[1]
-    assert n == 65536
-    # 65536 is not a multiple of 3: a frame of 21846 pixels would be 65538 bytes -- pad the strip to 66048 = 3 * 22016 bytes
-    pad = 3 * 22016 - n
-    cur = np.concatenate([cur, np.zeros((1, pad), np.uint8)], axis=1)
-    prev = np.concatenate([prev, np.zeros((1, pad), np.uint8)], axis=1)
-    for thr in (0, 20, 127, 128, 200, 255):
-        eo, exs, edf = oracle_pairs(po, cur, prev, thr)
-        with CUDACore(22016, 1, max_batch=1, threshold=thr) as core:
-            core.set_option(lib.OPT_DENSE_PAIRS, 2)
-            off, xs, df, _ = run_stream(core, cur, pair_prev=prev)
-            assert np.array_equal(off, eo) and np.array_equal(xs, exs) and np.array_equal(df, edf), thr
-    w, h, T = 320, 180, 6
-    n = 3 * w * h
-    d_c, d_p = _pairs_for("s0", n, T, w, h)
-    s_c, s_p = _pairs_for("webcam", n, T, w, h)
-    eo_d, exs_d, edf_d = oracle_pairs(po, d_c, d_p)
-    eo_s, exs_s, edf_s = oracle_pairs(po, s_c, s_p)
-    with CUDACore(w, h, max_batch=T) as core:
-        core.set_option(lib.OPT_DENSE_PAIRS, 2)
-        cap = int(eo_d[3]) + 7   # cuts inside frame 3
-        off, xs, df, _ = run_stream(core, d_c, pair_prev=d_p, capacity=cap)
-        assert np.array_equal(off, eo_d) and np.array_equal(xs, exs_d[:cap]) and np.array_equal(df, edf_d[:cap])
-        core.set_option(lib.OPT_DENSE_PAIRS, 1)
-        for c_, p_, eo, exs, edf in ((d_c, d_p, eo_d, exs_d, edf_d), (d_c, d_p, eo_d, exs_d, edf_d), (s_c, s_p, eo_s, exs_s, edf_s),
-                                     (s_c, s_p, eo_s, exs_s, edf_s), (d_c, d_p, eo_d, exs_d, edf_d)):
-            off, xs, df, _ = run_stream(core, c_, pair_prev=p_)
-            core.synchronize()
-            assert np.array_equal(off, eo) and np.array_equal(xs, exs) and np.array_equal(df, edf)
-
-
 def test_capacity_truncation_keeps_offsets_exact(po):
     base, frames = synth.webcam_stream(4, 64, 48, seed=8)
     eo, exs, edf, _ = po.diff_stream(frames, base)
