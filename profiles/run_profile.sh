@@ -14,7 +14,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 sha256sum $ROOT/cudavideostream_amd/libmi355diff.so > $OUT/lib.sha256
 python3 $ROOT/profiles/srchash.py > $OUT/src.sha256
-ARGS="bench.py --steps $STEPS --warmup 2 --no-cpu --no-pair --no-host-path --no-filters"
+ARGS="bench.py --steps $STEPS --warmup 2 --no-cpu --no-pair --no-host-path --no-filters --no-config5 --preheat-s 0.2 --steady-steps 100"
 cd $ROOT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || echo "trace failed"
 # counter passes run the C++ harness (same workload, same library, no Python).  They are NOT attempted on

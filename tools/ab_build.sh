@@ -18,7 +18,9 @@ mkdir -p $OUT/common
 pids=()
 for f in $ALL; do
   case " $VAR_FILES " in *" $f "*) continue;; esac
-  if [ ! -f $OUT/common/$f.o ] || [ $SRC/$f.hip -nt $OUT/common/$f.o ] || [ $SRC/internal.h -nt $OUT/common/$f.o ] || [ $SRC/pack_common.h -nt $OUT/common/$f.o ]; then
+  stale=0   # (every header counts: filters.hip includes the GENERATED median_net.h, everything includes lab.h and the C-ABI)
+  for h in $SRC/*.h $ROOT/include/mi355diff.h $SRC/$f.hip; do [ $h -nt $OUT/common/$f.o ] && stale=1; done
+  if [ ! -f $OUT/common/$f.o ] || [ $stale = 1 ]; then
     /opt/rocm/bin/hipcc $FLAGS -c -o $OUT/common/$f.o $SRC/$f.hip & pids+=($!)
   fi
 done
