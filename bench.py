@@ -28,8 +28,8 @@ config 5 (BASELINE.json configs[4], 4K frames dealt round-robin over the GPUs, R
          gather_gbps, ranks_seen, gather_verified, and parity of rank 0's copy of every rank's first and last frame against
          the oracle.  At N = 1 without a launcher: `config5_per_gpu` (one GPU's share of the same deal over 8 ranks).  The
          same shape as the WHOLE job: python bench.py --gpus 8 --shard roundrobin --width 3840 --height 2160 --batch 64
-timing : `value` = the W warm-up + K timed steps behind --preheat-s seconds (default 1) of the same step, untimed: a chip that
-         has been idle needs ~12 ms of load to reach its clocks and ~0.3 s to settle; the same W + K steps as the first GPU
+timing : `value` = the W warm-up + K timed steps behind --preheat-s seconds (default 3) of the same step, untimed: a chip that
+         has been idle needs ~12 ms of load to reach its clocks and a second or two to settle; the same W + K steps as the first GPU
          work of the process are reported beside it (`cold_start_window`: what rounds 1-5 printed), and `steady_state` (1000
          more steps) behind it.  roofline.frac is on the ALGORITHMIC bytes (2N + 5P); frac_actual / frac_of_achievable on the
          bytes the chip moved (counters) over 8 TB/s / over this board's plain streaming read.
@@ -42,8 +42,16 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# Under a launcher this process holds torch.distributed's and RCCL's stream pools AND two cores (the job's and config5's), each
+# with three streams that must run beside each other: the HIP runtime serves the streams of one priority class with at most
+# GPU_MAX_HW_QUEUES hardware queues (default 4) -- raised BEFORE the runtime starts, and the cores are created with
+# MI355_FLAG_OWN_QUEUES (include/mi355diff.h).  Measured with one rank under the launcher: headline 462 k frames/s without
+# either, 583 k with the flag; config5 0.52 of the roofline with the flag alone, 0.62 with both (profiles/README.md, r06k-r06p).
+if "RANK" in os.environ:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np   # noqa: E402
+import torch   # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -239,8 +247,8 @@ def parse():
                         "config5 object (the 4K sequence dealt over the ranks of this job + the gather, under a launcher)")
     p.add_argument("--config5-size", type=int, nargs=3, default=[3840, 2160, 64], metavar=("W", "H", "FRAMES"),
                    help="config5: frame size and frames per rank's shard (the tests take a small one)")
-    p.add_argument("--config5-steps", type=int, default=10, help="config5: timed passes over the shard")
-    p.add_argument("--preheat-s", type=float, default=1.0,
+    p.add_argument("--config5-steps", type=int, default=20, help="config5: timed passes over the shard")
+    p.add_argument("--preheat-s", type=float, default=3.0,
                    help="seconds of the same step, untimed, in front of the W warm-up + K timed steps (the chip's clock ramp and "
                         "first heating: DESIGN.md section 8); 0: none -- the W + K steps are then the first GPU work of the process, "
                         "as in rounds 1-5 (the default run reports that window too: cold_start_window)")
@@ -654,7 +662,11 @@ def main():
 
     # the core runs on its OWN stream: consecutive batches are then pipelined inside the library (csrc/core.hip,
     # run_batch); the timed region ends with a device-wide synchronisation
-    core = CUDACore(W, H, max_batch=B, device=local_rank)
+    # (a process that also holds torch.distributed / RCCL streams: the core's streams in a priority class of their own, or
+    # they share hardware queues with the framework's stream pools and batches no longer overlap: include/mi355diff.h)
+    from cudavideostream_amd import lib as _L
+    core_flags = _L.FLAG_OWN_QUEUES if (world > 1 or "RANK" in os.environ) else 0
+    core = CUDACore(W, H, max_batch=B, device=local_rank, flags=core_flags)
     core.set_state(base.cpu().numpy())
     torch.cuda.synchronize()   # the synthetic frames were made on torch's stream
 
@@ -733,8 +745,8 @@ def main():
     # 0.95-0.99 of the roofline while it is cool, dips ~0.2 s into the load and settles at its sustained level (0.91-0.92
     # over 18 s: profiles/r05ao_* ... r05as_*).  W + K steps as the first GPU work of a process (W = 5, K = 20: 12 ms) measure
     # that ramp, not the path: they are kept as `cold_start_window` (what rounds 1-5 printed as `value`).  The line's
-    # `value` is the same W + K steps behind --preheat-s seconds (default 1) of the same step, untimed: the state a stream
-    # that runs for longer than a second is in.  (`steady_state`, 1000 more steps behind the timed ones, stays as well.)
+    # `value` is the same W + K steps behind --preheat-s seconds (default 3) of the same step, untimed: the state a stream
+    # that runs for longer than a few seconds is in.  (`steady_state`, 1000 more steps behind the timed ones, stays as well.)
     cold = None
     preheat_steps = 0
     if args.preheat_s > 0:
@@ -838,6 +850,9 @@ def main():
                        "frames_per_step": B, "changed_bytes_per_frame": round(p_total / B, 1),
                        "parallelism": (f"frames round-robin over {world} ranks" if rr else
                                        f"{world} independent streams" if world > 1 else "1 stream"),
+                       "core_flags": ("MI355_FLAG_OWN_QUEUES: the core's streams in the least stream-priority class (hardware queues of "
+                                      "their own beside torch.distributed's / RCCL's stream pools); GPU_MAX_HW_QUEUES=%s"
+                                      % os.environ.get("GPU_MAX_HW_QUEUES") if core_flags else "0"),
                        "gather": ({"after": "after: one gather-v of the final batch to rank 0 behind the K timed steps (final_gather_ms, "
                                             "value_with_final_gather); --gather last puts it inside the timed region",
                                    "last": "last: one gather-v of the final batch to rank 0 inside the timed region"}.get(args.gather, args.gather)
@@ -1179,7 +1194,8 @@ def config5_across_ranks(args, dist, world, rank, local_rank, dev, cdev, rehears
     d_off = torch.zeros(B + 1, dtype=torch.int32, device=dev)
     d_xs = torch.empty(cap, dtype=torch.int32, device=dev)
     d_df = torch.empty(cap, dtype=torch.uint8, device=dev)
-    core = CUDACore(W, H, max_batch=B, device=local_rank)
+    from cudavideostream_amd import lib as _L
+    core = CUDACore(W, H, max_batch=B, device=local_rank, flags=_L.FLAG_OWN_QUEUES)
     torch.cuda.synchronize()
     group, impl = form_group(core, dist, world, rank, local_rank, cdev, rehearse)
     res["gather_impl"] = impl
@@ -1189,8 +1205,9 @@ def config5_across_ranks(args, dist, world, rank, local_rank, dev, cdev, rehears
         core.diff_pairs_batch(frames, prevs, B, d_off, d_xs, d_df, cap)
 
     warm_up(core, step, 3)
-    xch.run(d_off, d_xs, d_df)     # RCCL sets up this communicator's peer channels on first use
+    xch.run(d_off, d_xs, d_df)     # RCCL sets up this communicator's peer channels on first use (host-synchronised: the chip idles)
     xch.reset()
+    warm_up(core, step, 3)         # ... so the chip is put under this load again right in front of the timed passes
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -54,13 +54,13 @@ class CUDACore:
 
     def __init__(self, width, height, k=None, sample_mat_data=None, chars_px=None, chars_sz=None,
                  charset=CHARS_STR, threshold=LR_THRESHOLDS, max_batch=1, device=-1,
-                 noise_filter=False, visualizer=_l.VIS_NONE):
+                 noise_filter=False, visualizer=_l.VIS_NONE, flags=0):
         self._lib = _l.load()
         self.width, self.height = int(width), int(height)
         self.total = 3 * self.width * self.height
         self.max_batch = int(max_batch)
         cfg = _l.Config(self.width, self.height, int(threshold), self.max_batch, int(device),
-                        int(bool(noise_filter)), int(visualizer), 0)
+                        int(bool(noise_filter)), int(visualizer), int(flags))   # flags: lib.FLAG_*
         h = C.c_void_p()
         _l.check(self._lib.mi355_create(C.byref(cfg), C.byref(h)))
         self._h = h

@@ -159,6 +159,18 @@ int core_device(const ::mi355_core *c) { return c->device; }
 
 namespace {
 
+// A stream of the core.  MI355_FLAG_OWN_QUEUES: in the least stream-priority class, whose hardware queues no framework's
+// stream pool shares (include/mi355diff.h); else the default class.
+hipError_t make_stream(const mi355_core *c, hipStream_t *s) {
+    if (c->cfg.flags & MI355_FLAG_OWN_QUEUES) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+            return hipStreamCreateWithPriority(s, hipStreamNonBlocking, least);
+        (void)hipGetLastError();
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 template <class T>
 int dev_alloc(mi355_core *c, T **p, size_t count) {
     const size_t bytes = count * sizeof(T);
@@ -278,8 +290,8 @@ int setup_pipeline(mi355_core *c) {
     ok = ok && hipMalloc((void **)&s1.groff, T * expand_groups(c->ntiles) * 16) == hipSuccess;
     ok = ok && hipMalloc((void **)&s1.totals, (2 * T + 2) * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(s1.totals, 0, (2 * T + 2) * sizeof(uint32_t)) == hipSuccess;   // epoch 0 = never written; the ticket
-    ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&c->main2, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && make_stream(c, &c->side) == hipSuccess;
+    ok = ok && make_stream(c, &c->main2) == hipSuccess;
     for (int i = 0; i < mi355_core::kSets && ok; i++) {
         // device-scope release: these events only order kernels of this device against each other.  An event's default
         // is a SYSTEM-scope fence when it is recorded (caches written back and invalidated for the host's benefit),
@@ -494,7 +506,7 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (cfg->threshold < 0 || cfg->threshold > 255) return fail(MI355_ERR_INVALID, "threshold outside 0..255");
     if (cfg->max_batch < 1) return fail(MI355_ERR_INVALID, "max_batch < 1");
     if (cfg->visualizer < 0 || cfg->visualizer > 5) return fail(MI355_ERR_INVALID, "unknown visualizer");
-    if (cfg->flags != 0) return fail(MI355_ERR_INVALID, "flags: no flag is defined in this version of the library (must be 0)");
+    if (cfg->flags & ~MI355_FLAG_OWN_QUEUES) return fail(MI355_ERR_INVALID, "flags: unknown bit (MI355_FLAG_OWN_QUEUES is the only flag of this version of the library)");
     const uint64_t n64 = 3ull * (uint64_t)cfg->width * (uint64_t)cfg->height;
     if (n64 >= (1ull << 31)) return fail(MI355_ERR_INVALID, "frame larger than 2 GiB");
     // byte indices are int32 and batch offsets uint32 (the reference's h_xs / h_pos types)
@@ -530,7 +542,7 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     const size_t T = (size_t)cfg->max_batch, W = c->ntiles, N = c->n;
 
     int rc = use_device(c);
-    if (!rc) { e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipStreamCreate", e); }
+    if (!rc) { e = make_stream(c, &c->own_stream); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipStreamCreate", e); }
     c->stream = c->own_stream;
     for (int i = 0; i < mi355_core::kEvRing * mi355_core::kEvPer && !rc; i++) { e = hipEventCreateWithFlags(&c->ev[i / mi355_core::kEvPer][i % mi355_core::kEvPer], hipEventDisableSystemFence); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipEventCreate", e); }   // timing events: no system-scope fence (hip_runtime_api.h: "can improve the accuracy of timing measurements by avoiding the cost of cache writeback and invalidation")
     if (!rc && (e = init_gray_table()) != hipSuccess) rc = fail(MI355_ERR_HIP, "init_gray_table", e);

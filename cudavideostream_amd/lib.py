@@ -23,6 +23,7 @@ VIS_NONE, VIS_HEAT, VIS_RED, VIS_RED_OVERLAP, VIS_GRAY, VIS_BINARIZE = range(6)
 
 (OPT_PIPELINE, OPT_SPLIT_PCT, OPT_DENSE_PCT, OPT_CHAIN_HINT, OPT_PACK_BLOCKS, OPT_MEDIAN_ROWS,
  OPT_SCAN_EPOCH_LEFT) = range(1, 8)   # MI355_OPT_*
+FLAG_OWN_QUEUES = 1   # MI355_FLAG_*
 PREPARE_BATCHES, PREPARE_GRAY_CHAIN, PREPARE_RED_CLEAR, PREPARE_CONV_KXK, PREPARE_EXEC, PREPARE_ALL = 1, 2, 4, 8, 16, 31   # MI355_PREPARE_*
 
 

@@ -51,8 +51,18 @@ typedef struct mi355_config {
     int32_t device;     /* HIP device ordinal, or -1 for the current device */
     int32_t noise_filter; /* != 0: exec() runs the 3x3 convolution first (NOISE_FILTER, common.h:5) */
     int32_t visualizer; /* MI355_VIS_* used by exec() (NOISE_VISUALIZER, common.h:11) */
-    int32_t flags;      /* reserved: must be 0 (no flag is defined; anything else is refused) */
+    int32_t flags;      /* MI355_FLAG_* (below), or 0; unknown bits are refused */
 } mi355_config;
+/* MI355_FLAG_OWN_QUEUES: the core's streams (its own stream and the two side streams of pipelined batches) are created in the
+ * LEAST stream-priority class.  HIP serves the streams of one priority class of a process with at most GPU_MAX_HW_QUEUES (4)
+ * hardware queues; a process that also holds a framework's stream pools in the default class -- PyTorch creates 32 per class
+ * the moment torch.distributed / RCCL asks for one -- leaves the core's three streams sharing queues, and kernels that are
+ * meant to run BESIDE each other (the expansion of batch k and the pack kernel of batch k + 1) run one after the other:
+ * 462 k instead of 560-620 k frames/s at 1080p (round 6, profiles/README.md r06k / r06l).  No framework uses the least class,
+ * so there the three streams get hardware queues of their own (545-551 k with or without torch.distributed in the
+ * process; in a process WITHOUT other streams the default class is 1-2 % faster, hence a flag).  Set it in any process that
+ * also runs PyTorch collectives / RCCL / other HIP streams (bench.py does under a launcher). */
+#define MI355_FLAG_OWN_QUEUES 1
 
 /* ABI version of this header: bumped whenever an existing entry point changes its argument list (round 3 did that to
  * mi355_group_gather without a marker: a caller built against the older header still linked and passed shifted
@@ -64,7 +74,7 @@ typedef struct mi355_config {
  *      gone and cfg.flags must be 0; the environment variables MI355_SPLIT, MI355_DENSE_PCT, MI355_CHAIN_HINT and the
  *      undocumented tuning variables are no longer read (options below); + MI355_OPT_MEDIAN_ROWS, mi355_probe_hbm_write
  *      (additions)
- *   6  round 6: + mi355_prepare, MI355_OPT_SCAN_EPOCH_LEFT (additions only) */
+ *   6  round 6: + mi355_prepare, mi355_alloc_outputs, MI355_OPT_SCAN_EPOCH_LEFT, cfg.flags bit MI355_FLAG_OWN_QUEUES (additions only) */
 #define MI355_ABI_VERSION 6
 int mi355_abi_version(void);
 

@@ -56,7 +56,7 @@ def test_argument_validation_without_gpu(built):
     bad = lib.Config(64, 48, 300, 1, -1, 0, 0, 0)
     assert built.mi355_create(C.byref(bad), C.byref(h)) == lib.ERR_INVALID
     assert b"threshold" in built.mi355_last_error()
-    bad = lib.Config(64, 48, 20, 1, -1, 0, 0, 1)   # cfg.flags: no flag is defined (the experiment flags of rounds 2-4 are gone)
+    bad = lib.Config(64, 48, 20, 1, -1, 0, 0, 6)   # cfg.flags: MI355_FLAG_OWN_QUEUES (1) is the only flag; unknown bits are refused
     assert built.mi355_create(C.byref(bad), C.byref(h)) == lib.ERR_INVALID
     assert b"flags" in built.mi355_last_error()
     bad = lib.Config(1920, 1080, 20, 1000, -1, 0, 0, 0)  # 1000 * 6.2 MB >= 2^32

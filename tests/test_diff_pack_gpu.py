@@ -448,6 +448,25 @@ def test_scan_epoch_wrap_clears_the_totals(po, own_stream):
     _check_batches_against_oracle(outs, eo, exs, edf, T)
 
 
+def test_streams_in_their_own_priority_class_give_the_same_stream(po):
+    """MI355_FLAG_OWN_QUEUES: the core's three streams in the least stream-priority class (hardware queues of their own in a
+    process that also holds a framework's stream pools); pipelined batches back to back, every batch against the oracle."""
+    w, h, T, K = 320, 180, 6, 5
+    n = 3 * w * h
+    base, frames = synth.webcam_stream(T * K, w, h, seed=91)
+    eo, exs, edf, est = po.diff_stream(frames, base)
+    d_fr = to_dev(frames)
+    outs = [(torch.zeros(T + 1, dtype=torch.int32, device=DEV), torch.full((T * n,), -7, dtype=torch.int32, device=DEV),
+             torch.zeros(T * n, dtype=torch.uint8, device=DEV)) for _ in range(K)]
+    with CUDACore(w, h, max_batch=T, sample_mat_data=base, flags=lib.FLAG_OWN_QUEUES) as core:
+        torch.cuda.synchronize()
+        for k in range(K):
+            RawCore.diff_stream_batch(core, d_fr[k * T:(k + 1) * T], T, *outs[k], T * n)
+        core.synchronize()
+        assert np.array_equal(core.get_state(), est)
+    _check_batches_against_oracle(outs, eo, exs, edf, T)
+
+
 def test_prepare_leaves_nothing_to_allocate(po):
     """mi355_prepare(MI355_PREPARE_ALL): the second set of logs, the side streams and events of pipelined batches, the gray
     bytes of the fused binarize chain, the cleared red map's slice bounds and the K x K taps are made NOW; the entry points
@@ -731,5 +750,5 @@ def test_options_change_the_schedule_never_the_result(po):
                 core.set_option(k, v)
     import ctypes as C
     h_ = C.c_void_p()
-    cfg = lib.Config(8, 8, 20, 1, -1, 0, 0, 1)   # flags != 0: the experiment flags of rounds 2-4 are gone
+    cfg = lib.Config(8, 8, 20, 1, -1, 0, 0, 2)   # an unknown flag bit (the experiment flags of rounds 2-4 are gone; bit 0 is MI355_FLAG_OWN_QUEUES)
     assert lib.load().mi355_create(C.byref(cfg), C.byref(h_)) == lib.ERR_INVALID
