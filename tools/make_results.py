@@ -49,6 +49,11 @@ def main():
     if nb:
         row("value with --preheat-s 0", f"{k(nb['value'])} frames/s, {nb['ms_per_step']} ms, frac {nb['roofline']['frac']} (later in the same call: a warm chip)",
             D + " --preheat-s 0 ...", f"{TAG}_bench_no_preheat.json")
+    di = line(f"{TAG}_bench_default_invocation.json")
+    if di:
+        row("the default invocation (100 timed steps, 10 warm-up; later in the call: a warm chip)", f"{k(di['value'])} frames/s, {di['ms_per_step']} ms, frac "
+            f"{di['roofline']['frac']} / actual {di['roofline'].get('frac_actual')} / of achievable {di['roofline'].get('frac_of_achievable')}; steady_state {di['steady_state']['frac']}",
+            "python bench.py", f"{TAG}_bench_default_invocation.json")
     row("steady_state", f"{k(ss['frames_per_s'])} frames/s, {ss['ms_per_step']} ms, frac {ss['frac']} / actual {ss.get('frac_actual')} / of achievable "
         f"{ss.get('frac_of_achievable')} (1000 more steps behind the timed ones)", D, F)
     row("roofline.kernels[].avg_us", " / ".join(f"{x['avg_us']}" for x in r["kernels"]) + " µs: pack (two launches, the later end) / index / expansion, "
@@ -104,9 +109,12 @@ def main():
             "python bench.py --gpus 3 --rehearse-on-one-gpu --batch 64 ...", f"{TAG}_bench_rehearsal_3ranks_one_gpu.json")
     head = f"""# RESULTS — every key of the bench line, the command that prints it, the one file that holds it
 
-Generated by `tools/make_results.py` from the committed outputs of ONE `gpurun` call on ONE 1×MI355X box
-(`tools/exp/r06_final.sh`, log: `profiles/{TAG}_final_log.txt`: GPU suite, `smoke()`, `tests/soak.py 3000`, `tests/soak_chain.py 60`, then
-the lines below).  Boxes differ by ±5 % and a chip's state by more (DESIGN.md §6, §8): `BENCH_r06.json`, the driver's own run of
+Generated by `tools/make_results.py` from the committed outputs of two `gpurun` calls, a 1×MI355X box each: `tools/exp/r06_final.sh`
+(GPU suite, `smoke()`, `tests/soak.py 3000`, `tests/soak_chain.py 60`, every line below but the first command's, the `rocprofv3`
+passes) and, once that call's counters were committed as `profiles/pmc_summary.json`, `tools/exp/r06_final2.sh` (the whole GPU
+suite again: 268 passed; the first command, `profiles/{TAG}_bench.json`; `python bench.py` without arguments,
+`profiles/{TAG}_bench_default_invocation.json`: 100 timed steps on a chip that had been working for minutes -- the warm,
+sustained figure).  Log of both: `profiles/{TAG}_final_log.txt`.  Boxes differ by ±5 % and a chip's state by more (DESIGN.md §6, §8): `BENCH_r06.json`, the driver's own run of
 the first command on another box, will differ in the digits, not in the keys.  Experiments of the round (what was tried, kept,
 removed): `profiles/README.md` "Round 6"; rounds 1-5: `profiles/README.md` / `profiles/archive/`.
 
