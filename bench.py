@@ -886,7 +886,7 @@ def main():
                                                 "(what rounds 1-5 printed as `value`): it sits on the chip's clock ramp"}
         out["preheat"] = {"seconds": args.preheat_s, "steps": preheat_steps,
                           "note": "the same step, untimed, in front of the warm-up + timed steps whose rate is `value`: a chip that "
-                                  "has been idle needs ~12 ms of load to reach its clocks and ~0.3 s to its sustained state "
+                                  "has been idle needs ~12 ms of load to reach its clocks and a second or two to settle "
                                   "(profiles/r05ao-r05as); --preheat-s 0: none"}
         if world == 1 and not args.no_pair and not rr:
             out["pair_mode"] = pair_mode(args, core, frames, d_off, d_xs, d_df, cap, n)

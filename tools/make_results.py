@@ -54,6 +54,13 @@ def main():
         row("the default invocation (100 timed steps, 10 warm-up; later in the call: a warm chip)", f"{k(di['value'])} frames/s, {di['ms_per_step']} ms, frac "
             f"{di['roofline']['frac']} / actual {di['roofline'].get('frac_actual')} / of achievable {di['roofline'].get('frac_of_achievable')}; steady_state {di['steady_state']['frac']}",
             "python bench.py", f"{TAG}_bench_default_invocation.json")
+    try:
+        runs = [ln for ln in open(os.path.join(P, "r06q_eighteen_seconds.txt")).read().splitlines() if ln.startswith("run ")]
+        vals = [(float(ln.split()[2]), float(ln.split()[4]), float(ln.split()[7])) for ln in runs]
+        row("sustained over 18 s (40 000 timed steps, twice in a row on one box)", " then ".join(f"{k(v[0])} frames/s, {v[1]} ms, frac {v[2]}" for v in vals),
+            "python bench.py --steps 40000 --warmup 10 --preheat-s 0 ...", "r06q_eighteen_seconds.txt")
+    except Exception:   # noqa: BLE001
+        pass
     row("steady_state", f"{k(ss['frames_per_s'])} frames/s, {ss['ms_per_step']} ms, frac {ss['frac']} / actual {ss.get('frac_actual')} / of achievable "
         f"{ss.get('frac_of_achievable')} (1000 more steps behind the timed ones)", D, F)
     row("roofline.kernels[].avg_us", " / ".join(f"{x['avg_us']}" for x in r["kernels"]) + " µs: pack (two launches, the later end) / index / expansion, "
