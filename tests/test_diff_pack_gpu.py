@@ -467,6 +467,47 @@ def test_streams_in_their_own_priority_class_give_the_same_stream(po):
     _check_batches_against_oracle(outs, eo, exs, edf, T)
 
 
+@pytest.mark.parametrize("w,h,T", [(320, 180, 6), (1920, 1080, 8)])
+def test_alloc_outputs_gives_a_usable_pair(po, w, h, T):
+    """mi355_alloc_outputs: the index and the value array of the batch entry points as a pair placed for the dense expansion.
+    Small frames take plain allocations (1 draw); at 1080p x 8 frames the library probes candidate value arrays with its own
+    kernels on noise frames (the core's state and later results must not notice).  A dense and a sparse pair batch into the
+    pair, read back through mi355_download, against the oracle."""
+    import ctypes as C
+    n = 3 * w * h
+    cur = np.stack([synth.refrand_frame(n, 700 + t) for t in range(T)])
+    prev = np.stack([synth.refrand_frame(n, 800 + t) for t in range(T)])
+    base, frames = synth.webcam_stream(T, w, h, seed=5)
+    with CUDACore(w, h, max_batch=T, sample_mat_data=base) as core:
+        cap = T * n
+        d_xs, d_df, draws = core.alloc_outputs(cap)
+        assert d_xs and d_df and 1 <= draws <= 32
+        assert np.array_equal(core.get_state(), base)           # the probe batches are stateless pairs
+        d_off = torch.zeros(T + 1, dtype=torch.int32, device=DEV)
+
+        def fetch(total):
+            xs, df = np.empty(total, np.int32), np.empty(total, np.uint8)
+            L = lib.load()
+            lib.check(L.mi355_download(core._h, xs.ctypes.data_as(C.c_void_p), C.c_void_p(d_xs), 4 * total))
+            lib.check(L.mi355_download(core._h, df.ctypes.data_as(C.c_void_p), C.c_void_p(d_df), total))
+            return xs, df
+
+        core.diff_pairs_batch(to_dev(cur), to_dev(prev), T, d_off, d_xs, d_df, cap)
+        core.synchronize()
+        eo, exs, edf = oracle_pairs(po, cur, prev)
+        assert np.array_equal(d_off.cpu().numpy().view(np.uint32), eo)
+        xs, df = fetch(int(eo[-1]))
+        assert np.array_equal(xs, exs) and np.array_equal(df, edf)
+        core.diff_stream_batch(to_dev(frames), T, d_off, d_xs, d_df, cap)
+        core.synchronize()
+        eo, exs, edf, est = po.diff_stream(frames, base)
+        assert np.array_equal(d_off.cpu().numpy().view(np.uint32), eo)
+        xs, df = fetch(int(eo[-1]))
+        assert np.array_equal(xs, exs) and np.array_equal(df, edf) and np.array_equal(core.get_state(), est)
+        core.dev_free(d_xs)
+        core.dev_free(d_df)
+
+
 def test_prepare_leaves_nothing_to_allocate(po):
     """mi355_prepare(MI355_PREPARE_ALL): the second set of logs, the side streams and events of pipelined batches, the gray
     bytes of the fused binarize chain, the cleared red map's slice bounds and the K x K taps are made NOW; the entry points
