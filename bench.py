@@ -490,6 +490,12 @@ def rehearsal_env():
             "MOCK_RCCL_TIMEOUT_S": os.environ.get("MOCK_RCCL_TIMEOUT_S", "60")}
 
 
+def _device_sync():
+    """(a no-op without a GPU: tests/test_gather_gloo.py runs the Exchange over gloo with host tensors)"""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
 def payload_digest(o, xs, df):
     """[entries, sum of the offsets, weighted sums of the indices and of the differences] of one rank's packed batch."""
     pn = int(o[-1].item()) & 0xFFFFFFFF
@@ -518,7 +524,7 @@ class Exchange:
     def run(self, d_off, d_xs, d_df):
         """One gather, timed on its own (a host synchronisation either side: the call has one inside anyway,
         kernels.cu:507-508)."""
-        torch.cuda.synchronize()
+        _device_sync()
         tg = time.perf_counter()
         if self.group is not None:
             root = self.rank == 0
@@ -534,7 +540,7 @@ class Exchange:
             total = int(sum(totals))
             if self.rank == 0:
                 self.root = (index, xs_all, df_all)
-        torch.cuda.synchronize()
+        _device_sync()
         ms = (time.perf_counter() - tg) * 1e3
         self.ms += ms
         self.calls += 1
@@ -545,7 +551,7 @@ class Exchange:
         """Did the root receive what the ranks produced?  To be called right behind run(), before anything rewrites the
         ranks' arrays, outside every timed region: every rank digests its own (offsets, xs, diff), the digests travel
         over torch.distributed, rank 0 digests the segment it holds for every rank.  True / False on rank 0, None elsewhere."""
-        torch.cuda.synchronize()
+        _device_sync()
         mine = torch.tensor(payload_digest(d_off, d_xs, d_df), dtype=torch.int64, device=self.cdev)
         every = [torch.zeros_like(mine) for _ in range(self.world)]
         if self.world > 1:

@@ -212,3 +212,68 @@ def test_single_process_passthrough():
         assert gx.gather_index(off).shape == (1, 3)
     finally:
         dist.destroy_process_group()
+
+
+# ---- bench.py's own exchange object and config 5's round-robin bookkeeping, on the CPU ---------------------------------------
+def _config5_worker(rank, world, port, B, w, h, q):
+    """What bench.py::config5_across_ranks does with the GPU taken out: ONE sequence dealt round-robin over the ranks, every
+    rank's shard diffed against its raw predecessors (here by the oracle), bench.Exchange to rank 0 (its torch.distributed
+    form: no RCCL group), Exchange.verify, and rank 0's parity check of ITS copy through gather.roundrobin_order."""
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from oracle import pyoracle as po
+        n = 3 * w * h
+        mine = gx.roundrobin_frames(rank, world, B * world)
+        offs, xs_l, df_l = [0], [], []
+        for t in mine:
+            c, xs, df, _ = po.diff_pack(synth.webcam_frame(t, w, h, seed=31), synth.webcam_frame(t - 1, w, h, seed=31))
+            offs.append(offs[-1] + c); xs_l.append(xs); df_l.append(df)
+        total = offs[-1]
+        cap = total + 64
+        d_off = torch.tensor(offs, dtype=torch.int64).to(torch.int32)
+        d_xs = torch.zeros(cap, dtype=torch.int32); d_xs[:total] = torch.from_numpy(np.concatenate(xs_l))
+        d_df = torch.zeros(cap, dtype=torch.uint8); d_df[:total] = torch.from_numpy(np.concatenate(df_l))
+        cpu = torch.device("cpu")
+        xch = bench.Exchange(None, dist, world, rank, B, cap, cpu, cpu)
+        ms = xch.run(d_off, d_xs, d_df)
+        ok = xch.verify(d_off, d_xs, d_df)
+        assert ms >= 0 and xch.calls == 1 and xch.ranks_seen == world
+        if rank == 0:
+            assert ok is True
+            index, xs_all, df_all = xch.root
+            seg = gx.roundrobin_order(index, B * world)
+            par = True
+            for t in range(B * world):      # every frame of the sequence, not only the shards' first and last
+                c, xs, df, _ = po.diff_pack(synth.webcam_frame(t, w, h, seed=31), synth.webcam_frame(t - 1, w, h, seed=31))
+                a, b = seg[t]
+                par = par and b - a == c and np.array_equal(xs_all[a:b].numpy(), xs) and np.array_equal(df_all[a:b].numpy(), df)
+            # a corrupted copy must be noticed by verify()
+            xs_all[0] += 1
+            q.put((par, xch.bytes, xch.verify(d_off, d_xs, d_df)))
+        else:
+            assert ok is None
+            xch.verify(d_off, d_xs, d_df)      # (collective: rank 0 calls it a second time)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_exchange_and_config5_bookkeeping_on_cpu(world):
+    B, w, h = 3, 48, 32
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_config5_worker, args=(r, world, port, B, w, h, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    par, nbytes, corrupted = q.get(timeout=180)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert par is True and nbytes > 4 * (B + 1) * world and corrupted is False
