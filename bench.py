@@ -248,6 +248,9 @@ def parse():
     p.add_argument("--config5-size", type=int, nargs=3, default=[3840, 2160, 64], metavar=("W", "H", "FRAMES"),
                    help="config5: frame size and frames per rank's shard (the tests take a small one)")
     p.add_argument("--config5-steps", type=int, default=20, help="config5: timed passes over the shard")
+    p.add_argument("--own-queues", choices=["auto", "0", "1"], default="auto",
+                   help="MI355_FLAG_OWN_QUEUES on the cores: auto (default) = under a launcher only (a process that also holds "
+                        "torch.distributed's / RCCL's stream pools), 0 / 1 = never / always")
     p.add_argument("--preheat-s", type=float, default=3.0,
                    help="seconds of the same step, untimed, in front of the W warm-up + K timed steps (the chip's clock ramp and "
                         "first heating: DESIGN.md section 8); 0: none -- the W + K steps are then the first GPU work of the process, "
@@ -671,7 +674,7 @@ def main():
     # (a process that also holds torch.distributed / RCCL streams: the core's streams in a priority class of their own, or
     # they share hardware queues with the framework's stream pools and batches no longer overlap: include/mi355diff.h)
     from cudavideostream_amd import lib as _L
-    core_flags = _L.FLAG_OWN_QUEUES if (world > 1 or "RANK" in os.environ) else 0
+    core_flags = _L.FLAG_OWN_QUEUES if (args.own_queues == "1" or (args.own_queues == "auto" and (world > 1 or "RANK" in os.environ))) else 0
     core = CUDACore(W, H, max_batch=B, device=local_rank, flags=core_flags)
     core.set_state(base.cpu().numpy())
     torch.cuda.synchronize()   # the synthetic frames were made on torch's stream
