@@ -703,6 +703,12 @@ int mi355_set_option(mi355_core *c, int option, int value) {
         case MI355_OPT_SCAN_EPOCH_LEFT:   // tests: the index kernel's launch tag this many launches before its wrap
             if (value < 1 || value > (1 << 30)) return fail(MI355_ERR_INVALID, "MI355_OPT_SCAN_EPOCH_LEFT: 1..2^30");
             if (c->side) HIP_TRY(hipStreamSynchronize(c->side));
+            if (c->main2) HIP_TRY(hipStreamSynchronize(c->main2));
+            // every total goes with the jump: a tag set BACK (the option used twice before a wrap) would otherwise meet slots that
+            // still carry that very tag from an earlier launch, and the index kernel would take their stale totals for this launch's
+            // (found by tests/soak_chain.py in round 6: offsets of garbage, a red-map kernel walking 2^32 entries)
+            HIP_TRY(hipMemset(c->totals, 0, 2 * (size_t)c->cfg.max_batch * sizeof(uint32_t)));
+            if (c->set[1].totals) HIP_TRY(hipMemset(c->set[1].totals, 0, 2 * (size_t)c->cfg.max_batch * sizeof(uint32_t)));
             c->scan_epoch = kEpochWrap - 1 - (uint64_t)value;
             return MI355_OK;
         default: return fail(MI355_ERR_INVALID, "unknown option");

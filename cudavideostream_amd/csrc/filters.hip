@@ -688,7 +688,9 @@ constexpr uint32_t kRedSlice = 3072;   // 1024 pixels
 // a plain binary search (17 dependent probes at 1080p, all boundaries of all frames at once).
 __global__ __launch_bounds__(256) void k_red_bounds(const uint32_t *offsets, const int32_t *xs, uint32_t nbytes,
                                                     uint32_t nbounds, uint32_t *bounds) {
-    const uint32_t first = offsets[blockIdx.y], n = offsets[blockIdx.y + 1] - first;
+    // (a frame has at most nbytes entries: offsets that say otherwise -- a caller's bug -- must not send the search, and the
+    // slice kernel behind it, over billions of entries)
+    const uint32_t first = offsets[blockIdx.y], n = min(offsets[blockIdx.y + 1] - first, nbytes);
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
     if (j >= nbounds) return;
     const uint64_t tgt64 = (uint64_t)j * kRedSlice;

@@ -30,7 +30,7 @@ def oracle_pairs(cur, prev):
             np.concatenate(df) if df else np.empty(0, np.uint8))
 
 
-def run(rounds, seed, w=320, h=180, T=5, verbose=True):
+def run(rounds, seed, w=320, h=180, T=5, verbose=True, flags=0):
     rng = np.random.default_rng(seed)
     n = 3 * w * h
     k9 = po.gaussian_kernel(3, 1.5)
@@ -44,7 +44,7 @@ def run(rounds, seed, w=320, h=180, T=5, verbose=True):
     nout = 6
     outs = [(torch.zeros(T + 1, dtype=torch.int32, device=DEV), torch.empty(T * n, dtype=torch.int32, device=DEV),
              torch.empty(T * n, dtype=torch.uint8, device=DEV)) for _ in range(nout)]
-    core = CUDACore(w, h, k=k9, max_batch=T, sample_mat_data=base)
+    core = CUDACore(w, h, k=k9, max_batch=T, sample_mat_data=base, flags=flags)
     state = base.copy()
     own = True
     for rnd in range(rounds):
@@ -56,6 +56,10 @@ def run(rounds, seed, w=320, h=180, T=5, verbose=True):
             op = int(rng.integers(0, 7))
             if int(rng.integers(0, 24)) == 0:
                 op = 7       # (rarely: the oracle sorts 25 bytes per output byte)
+            if int(rng.integers(0, 16)) == 0:   # (round 6) mi355_prepare in the middle of queued work: blocking, changes nothing
+                core.prepare(int(rng.integers(1, 32)))
+            if int(rng.integers(0, 40)) == 0:   # (round 6) the index kernel's launch tag put in front of its wrap: the totals are cleared
+                core.set_option(lib.OPT_SCAN_EPOCH_LEFT, int(rng.integers(1, 4)))   # (set_option completes what is queued)
             f0 = int(rng.integers(0, 64 - 2 * T))
             o = outs[i]
             if op == 0:      # stream batch straight from the pool
@@ -112,7 +116,7 @@ def run(rounds, seed, w=320, h=180, T=5, verbose=True):
         if not np.array_equal(core.get_state(), state):
             print(f"MISMATCH in round {rnd} (state); seed {seed}")
             return False
-        if verbose and rnd % 100 == 0:
+        if verbose and rnd % 25 == 0:
             print(f"round {rnd} ok", flush=True)
     core.close()
     return True
@@ -121,6 +125,7 @@ def run(rounds, seed, w=320, h=180, T=5, verbose=True):
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 500
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 11
-    ok = run(rounds, seed) and run(max(rounds // 4, 1), seed + 100, w=640, h=360, T=4)
+    ok = (run(rounds, seed) and run(max(rounds // 4, 1), seed + 100, w=640, h=360, T=4)
+          and run(max(rounds // 4, 1), seed + 200, flags=lib.FLAG_OWN_QUEUES))   # the core's streams in their own priority class
     print("chain soak ok" if ok else "chain soak FAILED")
     sys.exit(0 if ok else 1)
