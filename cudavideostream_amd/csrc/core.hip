@@ -259,6 +259,19 @@ int need_gray1(mi355_core *c) {
     return dev_alloc(c, &c->gray1, c->gray1_stride * (size_t)c->cfg.max_batch);
 }
 
+// Every frame total of both log sets back to "never written" (the launch tags wrap, or a test moves them).  The caller has
+// synchronised the core's streams.  hipMemset of device memory may RETURN before it has run and runs on the null stream, which
+// the core's non-blocking streams are not ordered against: the first version cleared with it, and an index kernel launched
+// behind the call on the side stream could publish a total first and see it zeroed -- its reader then waited for that tag for
+// ever (tests/soak_chain.py, round 6).  The clears therefore go through the core's stream and the host waits for them.
+int clear_totals(mi355_core *c) {
+    const size_t bytes = 2 * (size_t)c->cfg.max_batch * sizeof(uint32_t);   // (the ticket behind them is 0 between launches)
+    HIP_TRY(hipMemsetAsync(c->totals, 0, bytes, c->stream));
+    if (c->set[1].totals) HIP_TRY(hipMemsetAsync(c->set[1].totals, 0, bytes, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MI355_OK;
+}
+
 // Slice bounds of the cleared red map (mi355_red_stream_batch, clear != 0), max_batch frames: made when first needed.
 int need_red_bounds(mi355_core *c) {
     if (c->red_bounds || c->n == 0) return MI355_OK;
@@ -289,7 +302,10 @@ int setup_pipeline(mi355_core *c) {
     ok = ok && hipMalloc((void **)&s1.meta, T * W * 16) == hipSuccess;
     ok = ok && hipMalloc((void **)&s1.groff, T * expand_groups(c->ntiles) * 16) == hipSuccess;
     ok = ok && hipMalloc((void **)&s1.totals, (2 * T + 2) * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipMemset(s1.totals, 0, (2 * T + 2) * sizeof(uint32_t)) == hipSuccess;   // epoch 0 = never written; the ticket
+    // (through the core's stream, and waited for: a plain hipMemset of device memory runs on the null stream, which the core's
+    // non-blocking streams are not ordered against -- clear_totals)
+    ok = ok && hipMemsetAsync(s1.totals, 0, (2 * T + 2) * sizeof(uint32_t), c->stream) == hipSuccess &&   // tag 0 = never written; the ticket
+         hipStreamSynchronize(c->stream) == hipSuccess;
     ok = ok && make_stream(c, &c->side) == hipSuccess;
     ok = ok && make_stream(c, &c->main2) == hipSuccess;
     for (int i = 0; i < mi355_core::kSets && ok; i++) {
@@ -453,9 +469,7 @@ int run_batch(mi355_core *c, bool pair, const void *d_cur, const void *d_prev, s
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->side) HIP_TRY(hipStreamSynchronize(c->side));
         if (c->main2) HIP_TRY(hipStreamSynchronize(c->main2));
-        const size_t words = 2 * (size_t)c->cfg.max_batch * sizeof(uint32_t);   // (the ticket behind them is 0 between launches)
-        HIP_TRY(hipMemset(c->totals, 0, words));
-        if (c->set[1].totals) HIP_TRY(hipMemset(c->set[1].totals, 0, words));
+        if (int rc = clear_totals(c)) return rc;
     }
     // (an own-stream batch leaves its total in pinned memory for the next calls' decisions -- stored by the index kernel
     // itself: a copy + an event behind every batch cost config 3's chain 4 %, the event's system-scope fence included)
@@ -555,7 +569,7 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (!rc) rc = dev_alloc(c, &c->meta, T * W);
     if (!rc) rc = dev_alloc(c, &c->groff, T * expand_groups(c->ntiles) * 4);   // one prefix per range of 16 tiles
     if (!rc) rc = dev_alloc(c, &c->totals, 2 * T + 2);   // T x {total, epoch} + the scan kernel's ticket counter
-    if (!rc) { e = hipMemset(c->totals, 0, (2 * T + 2) * sizeof(uint32_t)); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipMemset", e); }
+    if (!rc) { e = hipMemsetAsync(c->totals, 0, (2 * T + 2) * sizeof(uint32_t), c->own_stream); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipMemset", e); }
     if (!rc) rc = dev_alloc(c, &c->offsets, T + 1);
     if (!rc) rc = dev_alloc(c, &c->one_xs, N + 4);
     if (!rc) rc = dev_alloc(c, &c->one_diff, N + 16);
@@ -565,7 +579,10 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (!rc) rc = dev_alloc(c, &c->lut, 768 * 3);
     if (!rc) { e = hipHostMalloc((void **)&c->h_count, 2 * sizeof(uint32_t), hipHostMallocDefault); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipHostMalloc", e); }
     if (!rc) { e = hipHostMalloc((void **)&c->h_tot, sizeof(uint64_t), hipHostMallocDefault); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipHostMalloc", e); else *c->h_tot = 0; }
-    if (!rc) { e = hipMemset(c->state, 0, N + 16); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipMemset", e); }
+    if (!rc) { e = hipMemsetAsync(c->state, 0, N + 16, c->own_stream); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipMemset", e); }
+    // (the clears above went through the core's own stream -- a plain hipMemset runs on the null stream, which this stream is not
+    // ordered against, and may return before it has run -- and are complete before the core is handed out)
+    if (!rc) { e = hipStreamSynchronize(c->own_stream); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipStreamSynchronize", e); }
     if (!rc) {
         uint8_t lut[768 * 3] = {0};
         build_heat_lut(lut);
@@ -707,8 +724,7 @@ int mi355_set_option(mi355_core *c, int option, int value) {
             // every total goes with the jump: a tag set BACK (the option used twice before a wrap) would otherwise meet slots that
             // still carry that very tag from an earlier launch, and the index kernel would take their stale totals for this launch's
             // (found by tests/soak_chain.py in round 6: offsets of garbage, a red-map kernel walking 2^32 entries)
-            HIP_TRY(hipMemset(c->totals, 0, 2 * (size_t)c->cfg.max_batch * sizeof(uint32_t)));
-            if (c->set[1].totals) HIP_TRY(hipMemset(c->set[1].totals, 0, 2 * (size_t)c->cfg.max_batch * sizeof(uint32_t)));
+            if (int rc = clear_totals(c)) return rc;
             c->scan_epoch = kEpochWrap - 1 - (uint64_t)value;
             return MI355_OK;
         default: return fail(MI355_ERR_INVALID, "unknown option");

@@ -57,9 +57,13 @@ def run(rounds, seed, w=320, h=180, T=5, verbose=True, flags=0):
             if int(rng.integers(0, 24)) == 0:
                 op = 7       # (rarely: the oracle sorts 25 bytes per output byte)
             if int(rng.integers(0, 16)) == 0:   # (round 6) mi355_prepare in the middle of queued work: blocking, changes nothing
-                core.prepare(int(rng.integers(1, 32)))
+                mask = int(rng.integers(1, 32))
+                if os.environ.get("SOAK_PREPARE", "1") != "0":
+                    core.prepare(mask)
             if int(rng.integers(0, 40)) == 0:   # (round 6) the index kernel's launch tag put in front of its wrap: the totals are cleared
-                core.set_option(lib.OPT_SCAN_EPOCH_LEFT, int(rng.integers(1, 4)))   # (set_option completes what is queued)
+                left = int(rng.integers(1, 4))
+                if os.environ.get("SOAK_EPOCH", "1") != "0":
+                    core.set_option(lib.OPT_SCAN_EPOCH_LEFT, left)   # (set_option completes what is queued)
             f0 = int(rng.integers(0, 64 - 2 * T))
             o = outs[i]
             if op == 0:      # stream batch straight from the pool
