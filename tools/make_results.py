@@ -119,7 +119,7 @@ def main():
 Generated by `tools/make_results.py` from the committed outputs of two `gpurun` calls, a 1×MI355X box each: `tools/exp/r06_final.sh`
 (GPU suite, `smoke()`, `tests/soak.py 3000`, `tests/soak_chain.py 60`, every line below but the first command's, the `rocprofv3`
 passes) and, once that call's counters were committed as `profiles/pmc_summary.json`, `tools/exp/r06_final2.sh` (the whole GPU
-suite again: 268 passed; the first command, `profiles/{TAG}_bench.json`; `python bench.py` without arguments,
+suite again: 270 passed; the first command, `profiles/{TAG}_bench.json`; `python bench.py` without arguments,
 `profiles/{TAG}_bench_default_invocation.json`: 100 timed steps on a chip that had been working for minutes -- the warm,
 sustained figure).  Log of both: `profiles/{TAG}_final_log.txt`.  Boxes differ by ±5 % and a chip's state by more (DESIGN.md §6, §8): `BENCH_r06.json`, the driver's own run of
 the first command on another box, will differ in the digits, not in the keys.  Experiments of the round (what was tried, kept,
