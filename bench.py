@@ -646,10 +646,13 @@ def main():
     cdev = torch.device("cpu") if rehearse else dev
     if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run (also at N = 1)
         import torch.distributed as dist
+        import datetime
+        # (a rank that dies inside a collective must not hold the others for torch.distributed's default half an hour)
+        patience = datetime.timedelta(minutes=8)
         if rehearse:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=patience)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=patience)
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
@@ -1198,16 +1201,29 @@ def config5_across_ranks(args, dist, world, rank, local_rank, dev, cdev, rehears
                        f"{B}-frame shards resident in HBM, stateless diff against the raw predecessor + threshold(20) + pack, "
                        f"then ONE gather-v of all shards' streams to rank 0",
            "frames_per_rank": B, "steps": K5}
+    # every rank makes its shard; a rank that cannot (memory on a shared box) must not leave the others in the collectives below:
+    # the ranks agree first
     mine = gx.roundrobin_frames(rank, world, B * world)
-    frames = torch.stack([synth.webcam_frame(t, W, H, seed=seed, device=dev) for t in mine])
-    prevs = torch.stack([synth.webcam_frame(t - 1, W, H, seed=seed, device=dev) for t in mine])
-    cap = max(B * n // 8, 1 << 20)
-    d_off = torch.zeros(B + 1, dtype=torch.int32, device=dev)
-    d_xs = torch.empty(cap, dtype=torch.int32, device=dev)
-    d_df = torch.empty(cap, dtype=torch.uint8, device=dev)
-    from cudavideostream_amd import lib as _L
-    core = CUDACore(W, H, max_batch=B, device=local_rank, flags=_L.FLAG_OWN_QUEUES)
-    torch.cuda.synchronize()
+    core, why = None, ""
+    try:
+        frames = torch.stack([synth.webcam_frame(t, W, H, seed=seed, device=dev) for t in mine])
+        prevs = torch.stack([synth.webcam_frame(t - 1, W, H, seed=seed, device=dev) for t in mine])
+        cap = max(B * n // 8, 1 << 20)
+        d_off = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+        d_xs = torch.empty(cap, dtype=torch.int32, device=dev)
+        d_df = torch.empty(cap, dtype=torch.uint8, device=dev)
+        from cudavideostream_amd import lib as _L
+        core = CUDACore(W, H, max_batch=B, device=local_rank, flags=_L.FLAG_OWN_QUEUES)
+        torch.cuda.synchronize()
+    except Exception as e:   # noqa: BLE001
+        why = repr(e)[:160]
+        print(f"bench.py: rank {rank}: config5 could not be set up: {why}", file=sys.stderr, flush=True)
+    ready = torch.tensor([1 if core is not None else 0], device=cdev)
+    dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+    if int(ready.item()) == 0:
+        if core is not None:
+            core.close()
+        return {"skipped": f"a rank could not set its shard up ({why or 'another rank'})"} if rank == 0 else None
     group, impl = form_group(core, dist, world, rank, local_rank, cdev, rehearse)
     res["gather_impl"] = impl
     xch = Exchange(group, dist, world, rank, B, cap, dev, cdev)
