@@ -260,10 +260,12 @@ int need_gray1(mi355_core *c) {
 }
 
 // Every frame total of both log sets back to "never written" (the launch tags wrap, or a test moves them).  The caller has
-// synchronised the core's streams.  hipMemset of device memory may RETURN before it has run and runs on the null stream, which
-// the core's non-blocking streams are not ordered against: the first version cleared with it, and an index kernel launched
-// behind the call on the side stream could publish a total first and see it zeroed -- its reader then waited for that tag for
-// ever (tests/soak_chain.py, round 6).  The clears therefore go through the core's stream and the host waits for them.
+// synchronised the core's streams.  The first version cleared with plain hipMemset calls -- served by the null stream / the
+// runtime's own fill path, not by the core's streams -- and tests/soak_chain.py (round 6, the tag moved at random) then stopped
+// in the index kernel's reader, waiting for a total that had been published: 3 runs of 3; with the clears enqueued on the core's
+// stream and waited for, 5 of 5 ran to the end (tools/exp/r06s.sh).  What exactly let the published word be lost was not
+// established (a core created while the null stream is busy behaves the same with either form: test_core_created_while_the_
+// null_stream_is_busy); every clear of the core's own buffers goes the ordered way since.
 int clear_totals(mi355_core *c) {
     const size_t bytes = 2 * (size_t)c->cfg.max_batch * sizeof(uint32_t);   // (the ticket behind them is 0 between launches)
     HIP_TRY(hipMemsetAsync(c->totals, 0, bytes, c->stream));
@@ -302,8 +304,7 @@ int setup_pipeline(mi355_core *c) {
     ok = ok && hipMalloc((void **)&s1.meta, T * W * 16) == hipSuccess;
     ok = ok && hipMalloc((void **)&s1.groff, T * expand_groups(c->ntiles) * 16) == hipSuccess;
     ok = ok && hipMalloc((void **)&s1.totals, (2 * T + 2) * sizeof(uint32_t)) == hipSuccess;
-    // (through the core's stream, and waited for: a plain hipMemset of device memory runs on the null stream, which the core's
-    // non-blocking streams are not ordered against -- clear_totals)
+    // (through the core's stream, and waited for -- clear_totals)
     ok = ok && hipMemsetAsync(s1.totals, 0, (2 * T + 2) * sizeof(uint32_t), c->stream) == hipSuccess &&   // tag 0 = never written; the ticket
          hipStreamSynchronize(c->stream) == hipSuccess;
     ok = ok && make_stream(c, &c->side) == hipSuccess;
@@ -580,8 +581,7 @@ int mi355_create(const mi355_config *cfg, mi355_core **out) {
     if (!rc) { e = hipHostMalloc((void **)&c->h_count, 2 * sizeof(uint32_t), hipHostMallocDefault); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipHostMalloc", e); }
     if (!rc) { e = hipHostMalloc((void **)&c->h_tot, sizeof(uint64_t), hipHostMallocDefault); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipHostMalloc", e); else *c->h_tot = 0; }
     if (!rc) { e = hipMemsetAsync(c->state, 0, N + 16, c->own_stream); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipMemset", e); }
-    // (the clears above went through the core's own stream -- a plain hipMemset runs on the null stream, which this stream is not
-    // ordered against, and may return before it has run -- and are complete before the core is handed out)
+    // (the clears above went through the core's own stream -- clear_totals -- and are complete before the core is handed out)
     if (!rc) { e = hipStreamSynchronize(c->own_stream); if (e != hipSuccess) rc = fail(MI355_ERR_HIP, "hipStreamSynchronize", e); }
     if (!rc) {
         uint8_t lut[768 * 3] = {0};

@@ -510,6 +510,30 @@ def test_alloc_outputs_gives_a_usable_pair(po, w, h, T):
         core.dev_free(d_df)
 
 
+def test_core_created_while_the_null_stream_is_busy(po):
+    """The core's own buffers are cleared through the core's own stream and waited for (round 6: the launch tags' wrap path
+    cleared with plain hipMemset calls and the chain soak hung there).  This is the creation case: the null stream -- torch's
+    default stream -- is busy for about a second while a core is created, its state set and two pipelined batches run; the
+    state and both sets of totals must be what the batches expect whenever the clears ran."""
+    w, h, T = 320, 180, 4
+    n = 3 * w * h
+    base, frames = synth.webcam_stream(2 * T, w, h, seed=64)
+    eo, exs, edf, est = po.diff_stream(frames, base)
+    d_fr = to_dev(frames)
+    outs = [(torch.zeros(T + 1, dtype=torch.int32, device=DEV), torch.full((T * n,), -7, dtype=torch.int32, device=DEV),
+             torch.zeros(T * n, dtype=torch.uint8, device=DEV)) for _ in range(2)]
+    torch.cuda.synchronize()
+    torch.cuda._sleep(2_000_000_000)          # ~1 s of the null stream (cycles of the device clock)
+    with RawCore(w, h, max_batch=T, sample_mat_data=base) as core:
+        RawCore.diff_stream_batch(core, d_fr[:T], T, *outs[0], T * n)        # sets the pipelined mode up (second log set)
+        core.synchronize()
+        torch.cuda.synchronize()              # the null stream's work is over: anything that waited behind it has run now
+        RawCore.diff_stream_batch(core, d_fr[T:], T, *outs[1], T * n)
+        core.synchronize()
+        assert np.array_equal(core.get_state(), est)
+    _check_batches_against_oracle(outs, eo, exs, edf, T)
+
+
 def test_prepare_leaves_nothing_to_allocate(po):
     """mi355_prepare(MI355_PREPARE_ALL): the second set of logs, the side streams and events of pipelined batches, the gray
     bytes of the fused binarize chain, the cleared red map's slice bounds and the K x K taps are made NOW; the entry points
